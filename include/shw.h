@@ -1,0 +1,118 @@
+/* shw.h -- C ABI of the MI355X (gfx950) spherical sliced-Wasserstein / Chamfer hot path.
+ *
+ * The reference has no FFI layer: its "operator API" for this path is a set of dependency-injected
+ * Python callables.  The entry points below are what those callables bind to;
+ * each one names the reference code it replaces (paths relative to
+ * /root/reference/Point_Cloud_Resistration/losses/).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - the caller owns and allocates every buffer, including workspaces (sizes from the *_bytes
+ *     helpers); nothing is allocated, freed or synchronised inside;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value is a hipError_t cast to int: 0 = success, 1 (hipErrorInvalidValue) = bad
+ *     arguments / unsupported size, anything else = the launch error.
+ *   - clouds are fp32 row-major (pairs, points, 3); directions are fp32 (slices, 3, 2) orthonormal
+ *     2-frames, either one set per pair (u_pair_stride = slices*6) or shared (u_pair_stride = 0).
+ */
+#ifndef SHW_H
+#define SHW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHW_ABI_VERSION 1
+#define SHW_MAX_POINTS 8192 /* per cloud, per pair */
+
+/* ABI version of the loaded library (== SHW_ABI_VERSION of the header it was built from). */
+int shw_abi_version(void);
+
+/* Largest point count per cloud the sort kernels accept (SHW_MAX_POINTS). */
+int shw_max_points(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spherical sliced-Wasserstein, forward.
+ * Replaces: sliced_cost (max_spherical_sliced_w.py:251-286; batched _fast.py:258-295) =
+ *   projection (:270-271) + normalise (:274-275) + circle coordinate (:278-279) + per-slice sort
+ *   (:163-164 / :224-225) + circular OT solve (binary_search_circle :117-207 for p != 1,
+ *   emd1D_circle :210-247 for p == 1) -- everything up to, not including, the mean over slices.
+ *
+ *   xs (pairs, n, 3), xt (pairs, m, 3), dirs (see header comment), p >= 1.
+ *   slice_cost  (pairs*slices) fp32 out : circular OT cost W_p^p of every (pair, slice).
+ *   slice_shift (pairs*slices) int32 out, may be NULL : optimal cyclic shift k* of the sorted
+ *                target against the sorted source (p != 1), or the median level (p == 1).
+ * Supported in this ABI version: uniform weights; n == m for p != 1; any n, m for p == 1;
+ * 1 <= n, m <= SHW_MAX_POINTS.
+ */
+int shw_ssw_forward(const float* xs, const float* xt, const float* dirs,
+                    int pairs, int n, int m, int slices, long u_pair_stride, float p,
+                    float* slice_cost, int32_t* slice_shift, void* stream);
+
+/* Reduction of per-slice costs to the reference's scalars.
+ * Replaces: torch.mean(w1) (:286) per pair and the `w1 += mean(...)` loop over the batch
+ * (_fast.py:291-293).
+ *   pair_loss (pairs) out : scale * sum_l slice_cost[b, l]   (scale = 1/slices on one GPU, or
+ *                           1/global_slices when slices are sharded across ranks)
+ *   total     (2)     out : total[0] = sum_b pair_loss[b], total[1] = total[0] / pairs
+ * Deterministic (fixed-order shuffle + serial tree, no atomics).
+ */
+int shw_ssw_reduce(const float* slice_cost, int pairs, int slices, float scale,
+                   float* pair_loss, float* total, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spherical sliced-Wasserstein, forward + gradient in one pass.
+ * Replaces: autograd through Cost -> gather -> sort -> atan2 -> normalize -> matmul
+ * (max_spherical_sliced_w.py:207, :100-112, :163-164, :270-279); used by the notebooks' gradient
+ * flow (Flow_cube.ipynb:1381-1383) and by any trainer that back-propagates through the loss.
+ *
+ * Computes slice_cost / slice_shift as shw_ssw_forward and, additionally,
+ *   coef_s (pairs*slices*n) fp32 scratch : d cost(b,l) / d coord_s[b,l,i]  in ORIGINAL point order
+ *   coef_t (pairs*slices*m) fp32 scratch : d cost(b,l) / d coord_t[b,l,j]
+ * which shw_ssw_backward_points turns into d(sum_b pair_loss[b]) / d xs, / d xt:
+ *   grad_xs[b,i,:] = scale * sum_l coef_s[b,l,i] * (-b_ U[:,0] + a_ U[:,1]) / (2 pi (a_^2 + b_^2)),
+ *   (a_, b_) = U_l^T xs[b,i]   (SURVEY.md 8a row A9), likewise for xt.
+ * Deterministic: every gradient element is summed over slices in a fixed order by one thread.
+ */
+size_t shw_ssw_coef_bytes(int pairs, int n, int m, int slices);
+
+int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs,
+                         int pairs, int n, int m, int slices, long u_pair_stride, float p,
+                         float* slice_cost, int32_t* slice_shift,
+                         float* coef_s, float* coef_t, void* stream);
+
+int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
+                            const float* coef_s, const float* coef_t,
+                            int pairs, int n, int m, int slices, long u_pair_stride, float scale,
+                            float* grad_xs, float* grad_xt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chamfer distance (comparison baseline).
+ * Replaces: pytorch3d.loss.chamfer_distance with default arguments, as called at
+ * train_CD.py:123,161,327-328, main_rotation.py:203, test_ERROR.py:216 (third-party arithmetic,
+ * un-vendored and un-pinned: see DESIGN.md "parity unpinned").
+ *   x (pairs, n, 3), y (pairs, m, 3)
+ *   min_xy (pairs*n) fp32 out : min_j |x_i - y_j|^2 ;  nn_xy (pairs*n) int32 out : its argmin j
+ *   min_yx (pairs*m) fp32 out : min_i |x_i - y_j|^2 ;  nn_yx (pairs*m) int32 out : its argmin i
+ *   pair_loss (pairs) out : mean_i min_xy[b,i] + mean_j min_yx[b,j]   (deterministic reduction)
+ * All five outputs are required (the index arrays feed shw_chamfer_backward).
+ */
+int shw_chamfer_forward(const float* x, const float* y, int pairs, int n, int m,
+                        float* min_xy, int32_t* nn_xy, float* min_yx, int32_t* nn_yx,
+                        float* pair_loss, void* stream);
+
+/* grad of sum_b w[b]*pair_loss[b] (w = per-pair upstream gradient, device pointer, (pairs)).
+ * grad_x, grad_y must be zero-filled by the caller: the nearest-neighbour side of each term is
+ * scattered with float atomics (sum order, hence the last bits, may vary from run to run). */
+int shw_chamfer_backward(const float* x, const float* y, const int32_t* nn_xy, const int32_t* nn_yx,
+                         const float* w, int pairs, int n, int m,
+                         float* grad_x, float* grad_y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHW_H */

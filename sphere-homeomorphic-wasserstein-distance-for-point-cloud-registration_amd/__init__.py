@@ -1,0 +1,11 @@
+"""MI355X-native spherical sliced-Wasserstein registration loss (+ Chamfer baseline).
+
+Importable as `importlib.import_module("sphere-homeomorphic-wasserstein-distance-for-point-cloud-registration_amd")`
+or through the top-level alias module `shw_amd`."""
+from . import _lib
+from .chamfer import chamfer_distance, chamfer_pair_losses
+from .ssw import (draw_directions, sliced_cost, sliced_wasserstein_sphere, sliced_wasserstein_sphere_fast,
+                  ssw_pair_losses)
+
+__all__ = ["_lib", "chamfer_distance", "chamfer_pair_losses", "draw_directions", "sliced_cost", "sliced_wasserstein_sphere", "sliced_wasserstein_sphere_fast",
+           "ssw_pair_losses"]

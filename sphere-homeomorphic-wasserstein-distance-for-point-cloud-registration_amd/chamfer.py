@@ -1,0 +1,75 @@
+"""Chamfer baseline with the call shape the reference uses for pytorch3d.loss.chamfer_distance
+(train_CD.py:123,161; main_rotation.py:203; test_ERROR.py:216):
+
+    loss, _ = chamfer_distance(x, y)                       # batch mean
+    loss = chamfer_distance(x, y, batch_reduction="sum")[0]
+
+Defaults restated from pytorch3d's documented behaviour (squared-L2 nearest neighbour both ways,
+point_reduction="mean", the two directions added).  pytorch3d is neither vendored nor version-pinned
+by the reference and is not installed: parity for this function is UNPINNED."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ssw import _check_cloud, _stream_ptr
+
+
+class _ChamferPairs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        B, n, _ = x.shape
+        m = y.shape[1]
+        dev = x.device
+        xc, yc = x.contiguous(), y.contiguous()
+        min_xy = torch.empty(B * n, dtype=torch.float32, device=dev)
+        min_yx = torch.empty(B * m, dtype=torch.float32, device=dev)
+        nn_xy = torch.empty(B * n, dtype=torch.int32, device=dev)
+        nn_yx = torch.empty(B * m, dtype=torch.int32, device=dev)
+        pair = torch.empty(B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.shw_chamfer_forward(xc.data_ptr(), yc.data_ptr(), B, n, m, min_xy.data_ptr(),
+                                               nn_xy.data_ptr(), min_yx.data_ptr(), nn_yx.data_ptr(),
+                                               pair.data_ptr(), _stream_ptr(dev)), "shw_chamfer_forward")
+        ctx.save_for_backward(xc, yc, nn_xy, nn_yx)
+        return pair
+
+    @staticmethod
+    def backward(ctx, g_pair):
+        lib = _lib.load()
+        xc, yc, nn_xy, nn_yx = ctx.saved_tensors
+        B, n, _ = xc.shape
+        m = yc.shape[1]
+        dev = xc.device
+        gx = torch.zeros_like(xc)
+        gy = torch.zeros_like(yc)
+        w = g_pair.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.shw_chamfer_backward(xc.data_ptr(), yc.data_ptr(), nn_xy.data_ptr(), nn_yx.data_ptr(),
+                                                w.data_ptr(), B, n, m, gx.data_ptr(), gy.data_ptr(),
+                                                _stream_ptr(dev)), "shw_chamfer_backward")
+        return gx, gy
+
+
+def chamfer_pair_losses(x, y):
+    """(B,n,3), (B,m,3) -> (B,) per-pair Chamfer distances."""
+    _check_cloud("x", x)
+    _check_cloud("y", y)
+    if x.dim() != 3 or y.dim() != 3 or x.shape[0] != y.shape[0]:
+        raise ValueError("x and y must be (B,n,3) and (B,m,3) with the same B")
+    return _ChamferPairs.apply(x, y)
+
+
+def chamfer_distance(x, y, batch_reduction="mean", point_reduction="mean"):
+    """Returns (loss, None) like pytorch3d (the second slot is the normals loss, unused by the reference)."""
+    if point_reduction != "mean":
+        raise ValueError("only point_reduction='mean' (the reference's usage) is implemented")
+    pair = chamfer_pair_losses(x, y)
+    if batch_reduction == "mean":
+        return pair.mean(), None
+    if batch_reduction == "sum":
+        return pair.sum(), None
+    if batch_reduction is None:
+        return pair, None
+    raise ValueError(f"batch_reduction must be 'mean', 'sum' or None, got {batch_reduction!r}")

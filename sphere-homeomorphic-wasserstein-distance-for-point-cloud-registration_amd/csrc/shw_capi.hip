@@ -1,0 +1,107 @@
+// shw_capi.hip -- the extern "C" boundary (include/shw.h): argument validation, dispatch, and the
+// small deterministic reduction kernels.
+#include "ssw_common.hpp"
+
+namespace shw {
+
+// ---------------------------------------------------------------------------------------------
+// reductions: per-pair scaled sum over slices, then total over pairs.  Fixed order, no atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ssw_reduce_pairs_kernel(const float* __restrict__ slice_cost, int slices,
+                                                               float scale, float* __restrict__ pair_loss) {
+  __shared__ float part[4];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int l = threadIdx.x; l < slices; l += 256) acc += slice_cost[(long)b * slices + l];
+  acc = wave_sum(acc, lane);
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) pair_loss[b] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+}
+
+__global__ __launch_bounds__(64) void ssw_reduce_total_kernel(const float* __restrict__ pair_loss, int pairs,
+                                                              float* __restrict__ total) {
+  const int lane = threadIdx.x;
+  float acc = 0.f;
+  for (int b = lane; b < pairs; b += 64) acc += pair_loss[b];
+  acc = wave_sum(acc, lane);
+  if (lane == 0) {
+    total[0] = acc;
+    total[1] = acc / (float)pairs;
+  }
+}
+
+}  // namespace shw
+
+extern "C" {
+
+int shw_abi_version(void) { return SHW_ABI_VERSION; }
+int shw_max_points(void) { return SHW_MAX_POINTS; }
+
+int shw_ssw_forward(const float* xs, const float* xt, const float* dirs, int pairs, int n, int m, int slices,
+                    long u_pair_stride, float p, float* slice_cost, int32_t* slice_shift, void* stream) {
+  if (!xs || !xt || !dirs || !slice_cost) return (int)hipErrorInvalidValue;
+  if (pairs < 0 || slices < 0 || n < 1 || m < 1 || n > SHW_MAX_POINTS || m > SHW_MAX_POINTS) return (int)hipErrorInvalidValue;
+  if (!(p >= 1.f)) return (int)hipErrorInvalidValue;
+  if (u_pair_stride != 0 && u_pair_stride < (long)slices * 6) return (int)hipErrorInvalidValue;
+  if (p != 1.f && n != m) return (int)hipErrorInvalidValue;       // general quantile merge: next ABI version
+  if (pairs == 0 || slices == 0) return 0;
+  shw::SswArgs A{};
+  A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = slice_shift;
+  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride;
+  A.p = p; A.p_int = shw::small_integer_power(p);
+  if (p == 1.f) return shw::dispatch_level_median(A, (hipStream_t)stream);
+  return shw::dispatch_forward(A, (hipStream_t)stream);
+}
+
+int shw_ssw_reduce(const float* slice_cost, int pairs, int slices, float scale, float* pair_loss, float* total,
+                   void* stream) {
+  if (!slice_cost || !pair_loss || pairs < 0 || slices < 0) return (int)hipErrorInvalidValue;
+  if (pairs == 0) return 0;
+  hipLaunchKernelGGL(shw::ssw_reduce_pairs_kernel, dim3(pairs), dim3(256), 0, (hipStream_t)stream, slice_cost, slices,
+                     scale, pair_loss);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  if (total) {
+    hipLaunchKernelGGL(shw::ssw_reduce_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pair_loss, pairs, total);
+    rc = (int)hipGetLastError();
+  }
+  return rc;
+}
+
+size_t shw_ssw_coef_bytes(int pairs, int n, int m, int slices) {
+  if (pairs < 0 || n < 0 || m < 0 || slices < 0) return 0;
+  return (size_t)pairs * (size_t)slices * ((size_t)n + (size_t)m) * sizeof(float);
+}
+
+int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs, int pairs, int n, int m, int slices,
+                         long u_pair_stride, float p, float* slice_cost, int32_t* slice_shift, float* coef_s,
+                         float* coef_t, void* stream) {
+  if (!xs || !xt || !dirs || !slice_cost || !coef_s || !coef_t) return (int)hipErrorInvalidValue;
+  if (pairs < 0 || slices < 0 || n < 1 || m < 1 || n > SHW_MAX_POINTS || m > SHW_MAX_POINTS) return (int)hipErrorInvalidValue;
+  if (!(p >= 1.f)) return (int)hipErrorInvalidValue;
+  if (u_pair_stride != 0 && u_pair_stride < (long)slices * 6) return (int)hipErrorInvalidValue;
+  if (p != 1.f && n != m) return (int)hipErrorInvalidValue;
+  if (pairs == 0 || slices == 0) return 0;
+  shw::SswArgs A{};
+  A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = slice_shift;
+  A.coef_s = coef_s; A.coef_t = coef_t;
+  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride;
+  A.p = p; A.p_int = shw::small_integer_power(p);
+  if (p == 1.f) return shw::dispatch_level_median(A, (hipStream_t)stream);
+  return shw::dispatch_forward_grad(A, (hipStream_t)stream);
+}
+
+int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
+                            const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride, float scale,
+                            float* grad_xs, float* grad_xt, void* stream) {
+  if (!xs || !xt || !dirs || !coef_s || !coef_t || !grad_xs || !grad_xt) return (int)hipErrorInvalidValue;
+  if (pairs < 0 || slices < 0 || n < 1 || m < 1) return (int)hipErrorInvalidValue;
+  if (pairs == 0) return 0;
+  if (pairs > 65535) return (int)hipErrorInvalidValue;
+  return shw::launch_backward_points(xs, xt, dirs, coef_s, coef_t, pairs, n, m, slices, u_pair_stride, scale, grad_xs,
+                                     grad_xt, (hipStream_t)stream);
+}
+
+}  // extern "C"

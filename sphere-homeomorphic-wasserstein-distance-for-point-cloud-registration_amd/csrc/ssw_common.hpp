@@ -1,0 +1,272 @@
+// ssw_common.hpp -- shared device code of the spherical sliced-Wasserstein hot path for MI355X (gfx950, wave64).
+//
+// One 64-lane wavefront owns one (pair, slice): it projects both clouds of the pair onto the
+// slice's great circle, sorts both coordinate arrays in registers (wave_sort.hpp), parks the sorted
+// target in LDS and solves the circular optimal-transport problem against the sorted source that
+// stays in registers.  No barrier, no inter-wave communication, no MFMA (there is no contraction).
+//
+// Reference being replaced (paths relative to /root/reference/Point_Cloud_Resistration/losses/):
+//   sliced_cost            max_spherical_sliced_w.py:251-286, _fast.py:258-295
+//   binary_search_circle   :117-207   (p != 1)      emd1D_circle :210-247 (p == 1)
+// The p != 1 solve uses the equivalence of SURVEY.md 8a row A8: for n == m and uniform weights the
+// value the reference's bisection converges to is  min_k c(k),
+//     c(k) = (1/n) sum_i |u_(i) - v_ext(i+k)|^p ,  v_ext(q) = v_(q mod n) + floor(q/n),
+// a convex sequence in k.  The kernel starts at k0 = round(sum u - sum v) (exact minimiser when the
+// target atoms are equally spaced, since sum_i (u_(i) - v_ext(i+k)) = sum u - sum v - k) and walks
+// the convex sequence by galloping + bisection on the sign of c(k+1) - c(k).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/shw.h"
+#include "wave_sort.hpp"
+
+namespace shw {
+
+
+struct SswArgs {
+  const float* xs;
+  const float* xt;
+  const float* dirs;
+  float* slice_cost;
+  int32_t* slice_shift;
+  float* coef_s;   // forward_grad only
+  float* coef_t;
+  int pairs, n, m, slices;
+  long u_pair_stride;
+  float p;
+  int p_int;       // p if p is a small integer (2..8), else 0
+  int num_groups;  // workgroups launched (for the XCD remap)
+};
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware workgroup renumbering: hardware deals workgroups round-robin over the 8 XCDs
+// (blockIdx % 8 labels the XCD); give every XCD one contiguous range of (pair, slice) work so the
+// two clouds of a pair are fetched into ONE XCD's L2 instead of eight.  Bijective for any count.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// circle coordinate of one projected point (reference :274-279):
+//     coord = (atan2(-b, -a) + pi) / (2 pi)
+// F.normalize (:274-275) is a positive rescale and cannot change the angle, so it is skipped.
+// atan2 is evaluated as atan(min/max) with a degree-17 odd minimax polynomial
+// (t + t^3 Q(t^2), |error| <= 7e-8 rad = 1.2 ulp on [0,1]) and octant fix-ups that follow the IEEE
+// signed-zero rules the reference relies on: a = b = +0 gives atan2(-0,-0) = -pi, i.e. coord 0.
+// Domain note: |a|,|b| below 1e-37 (denormal-scale projections) are treated as if max(|a|,|b|) were
+// 1e-37, i.e. the angle of such a vector is not resolved; exact zeros are handled exactly.
+__device__ __forceinline__ float circle_coord(float a, float b) {
+  const float ax = fabsf(a), ay = fabsf(b);
+  const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+  const float rc = __builtin_amdgcn_rcpf(mx);
+  float t = mn * rc;
+  t = fmaf(fmaf(-mx, t, mn), rc, t);               // one Newton step: t = mn/mx to ~0.5 ulp
+  const float s = t * t;
+  float q = 2.6222439483e-03f;
+  q = fmaf(q, s, -1.5132533386e-02f);
+  q = fmaf(q, s, 4.1121855378e-02f);
+  q = fmaf(q, s, -7.3667056859e-02f);
+  q = fmaf(q, s, 1.0573931783e-01f);
+  q = fmaf(q, s, -1.4185975492e-01f);
+  q = fmaf(q, s, 1.9990396500e-01f);
+  q = fmaf(q, s, -3.3332985640e-01f);
+  float r = fmaf(t * s, q, t);                     // atan(mn/mx) in [0, pi/4]
+  r = (ay > ax) ? 1.57079637050628662f - r : r;    // angle from the x-axis, [0, pi/2]
+  // x = -a is "negative" (incl. -0) exactly when the sign bit of a is clear
+  r = (__builtin_bit_cast(int, a) >= 0) ? 3.14159274101257324f - r : r;
+  const float ang = copysignf(r, -b);              // sign of y = -b (incl. signed zero)
+  return (ang + 3.14159274101257324f) * 0.159154936671257019f;
+}
+
+// |d|^p.  PMODE 2: p == 2 (the reference's own call sites all use p = 2); PMODE 0: any p >= 1,
+// small integer powers by repeated multiplication, otherwise powf.
+template <int PMODE>
+__device__ __forceinline__ float pow_abs(float d, float p, int p_int) {
+  if constexpr (PMODE == 2) {
+    return d * d;
+  } else {
+    const float a = fabsf(d);
+    if (p_int > 0) {
+      float r = a;
+      for (int i = 1; i < p_int; ++i) r *= a;
+      return r;
+    }
+    return powf(a, p);
+  }
+}
+
+// d/dD |D|^p
+template <int PMODE>
+__device__ __forceinline__ float dpow_abs(float d, float p, int p_int) {
+  if constexpr (PMODE == 2) {
+    return 2.f * d;
+  } else {
+    const float a = fabsf(d);
+    float r;
+    if (p_int > 0) {
+      r = 1.f;
+      for (int i = 1; i < p_int; ++i) r *= a;
+    } else {
+      r = (a > 0.f) ? powf(a, p - 1.f) : 0.f;
+    }
+    return (a > 0.f) ? copysignf(p * r, d) : 0.f;
+  }
+}
+
+// sorted target in LDS: sorted position q lives at [(q % EPT) * 64 + q / EPT]  (= register r of
+// lane q/EPT, written with one conflict-free ds_write per register).
+template <int EPT>
+__device__ __forceinline__ int lds_slot(int q) {
+  constexpr int LOG = __builtin_ctz(EPT);
+  return ((q & (EPT - 1)) << 6) + (q >> LOG);
+}
+
+// v_ext(q) for q in [-2n, 3n): branch-free wrap onto [0, n) with the turn offset (two turns each
+// way: the shift k ranges over [-n, n] and its neighbours k-1, k+1 are evaluated alongside)
+template <int EPT>
+__device__ __forceinline__ float target_unrolled(const float* vbuf, int q, int n) {
+  const int t1 = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
+  q -= t1 * n;
+  const int t2 = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
+  q -= t2 * n;
+  return vbuf[lds_slot<EPT>(q)] + (float)(t1 + t2);
+}
+
+// c(k-1), c(k), c(k+1) (sums, not yet divided by n), valid in every lane.
+// Lane owns sorted positions e0 .. e0+EPT-1 and needs v_ext(e0+k-1 .. e0+k+EPT): a sliding window,
+// fetched 8 positions at a time to bound the registers in flight.
+template <int EPT, int PMODE>
+__device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float* vbuf, int lane, int n,
+                                             int k, float p, int p_int, float& cm, float& c0, float& cp) {
+  float sm = 0.f, s0 = 0.f, sp = 0.f;
+  const int e0 = lane * EPT;
+  const int last = n - 1;
+  float prev = target_unrolled<EPT>(vbuf, min(e0, last) + k - 1, n);
+  float cur = target_unrolled<EPT>(vbuf, min(e0, last) + k, n);
+  constexpr int CH = EPT < 8 ? EPT : 8;
+#pragma unroll
+  for (int r0 = 0; r0 < EPT; r0 += CH) {
+    float nxt[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) nxt[j] = target_unrolled<EPT>(vbuf, min(e0 + r0 + j, last) + k + 1, n);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const bool live = (e0 + r0 + j) < n;
+      const float a = pow_abs<PMODE>(u[r0 + j] - prev, p, p_int);
+      const float b = pow_abs<PMODE>(u[r0 + j] - cur, p, p_int);
+      const float c = pow_abs<PMODE>(u[r0 + j] - nxt[j], p, p_int);
+      sm += live ? a : 0.f;
+      s0 += live ? b : 0.f;
+      sp += live ? c : 0.f;
+      prev = cur;
+      cur = nxt[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cm = wave_sum(sm, lane);
+  c0 = wave_sum(s0, lane);
+  cp = wave_sum(sp, lane);
+}
+
+// Minimise the convex sequence c(k), |k| <= n (theta in [-1, 1], the reference's bracket :174-177).
+// Returns k*, writes c(k*) (sum form).
+template <int EPT, int PMODE>
+__device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* vbuf, int lane, int n,
+                                           float sum_u, float sum_v, float p, int p_int, float& best) {
+  int lo = -n, hi = n;
+  float guess = rintf(sum_u - sum_v);
+  guess = fminf(fmaxf(guess, (float)lo), (float)hi);
+  int k = __builtin_amdgcn_readfirstlane((int)guess);
+  bool lo_tight = false, hi_tight = false;
+  int step = 1;
+  float cm, c0, cp;
+  // every iteration removes k from [lo, hi]; galloping doubles, bisection halves: <= ~2 log2(2n)+2
+  // iterations.  The hard cap only guards against non-finite input (comparisons all false -> exit).
+  for (int it = 0; it < 64; ++it) {
+    shift_costs3<EPT, PMODE>(u, vbuf, lane, n, k, p, p_int, cm, c0, cp);
+    const bool right = (cp < c0) && (k < hi);
+    const bool left = !right && (cm < c0) && (k > lo);
+    if (!right && !left) break;
+    if (right) {
+      lo = k + 1;
+      lo_tight = true;
+      if (hi_tight) { k = lo + ((hi - lo) >> 1); }
+      else { k = min(k + step, hi); step <<= 1; }
+    } else {
+      hi = k - 1;
+      hi_tight = true;
+      if (lo_tight) { k = lo + ((hi - lo) >> 1); }
+      else { k = max(k - step, lo); step <<= 1; }
+    }
+    k = __builtin_amdgcn_readfirstlane(k);
+  }
+  best = c0;
+  return k;
+}
+
+// Project the cloud onto the slice's circle: lane owns points r*64 + lane (coalesced 12-byte
+// records).  Padding keys are +inf so that they sort behind every real coordinate.
+template <int EPT>
+__device__ __forceinline__ float load_coords(const float* __restrict__ X, int count, int lane,
+                                             const float (&U)[6], float (&key)[EPT]) {
+  float acc = 0.f;
+  constexpr int CH = EPT < 8 ? EPT : 8;            // 8 points (24 loads) in flight per lane
+#pragma unroll
+  for (int r0 = 0; r0 < EPT; r0 += CH) {
+    float px[CH], py[CH], pz[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int i = min((r0 + j) * kWave + lane, count - 1);   // clamp: branch-free, always in bounds
+      px[j] = X[3 * i]; py[j] = X[3 * i + 1]; pz[j] = X[3 * i + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int i = (r0 + j) * kWave + lane;
+      // "+ 0.f": a sum that starts from +0 like the reference's matmul accumulator (:270), so that an
+      // all-zero point projects to (+0, +0) -- never -0 -- and lands on coordinate 0 (G4 fixture)
+      const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], px[j] * U[0])) + 0.f;
+      const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], px[j] * U[1])) + 0.f;
+      const float c = circle_coord(a, b);
+      acc += (i < count) ? c : 0.f;
+      key[r0 + j] = (i < count) ? c : __builtin_inff();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers shared by the per-kernel translation units
+// ---------------------------------------------------------------------------------------------
+inline int small_integer_power(float p) {
+  const int q = (int)p;
+  return ((float)q == p && q >= 2 && q <= 8) ? q : 0;
+}
+
+inline int next_pow2(int v) {
+  int r = 1;
+  while (r < v) r <<= 1;
+  return r;
+}
+
+
+// size class: registers per lane (EPT) for the padded point count
+inline int ept_for(int n, int m) {
+  const int padded = next_pow2(n > m ? n : m);
+  return padded <= 64 ? 1 : padded / 64;
+}
+
+// dispatchers, one per translation unit (SswArgs validated by the C entry points in shw_capi.hip)
+int dispatch_forward(SswArgs& A, hipStream_t stream);        // shw_ssw_fwd.hip   p != 1, loss only
+int dispatch_forward_grad(SswArgs& A, hipStream_t stream);   // shw_ssw_grad.hip  p != 1, loss + coefficients
+int dispatch_level_median(SswArgs& A, hipStream_t stream);   // shw_ssw_p1.hip    p == 1 (coef_s != NULL: + coefficients)
+int launch_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
+                           const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride,
+                           float scale, float* grad_xs, float* grad_xt, hipStream_t stream);
+
+}  // namespace shw

@@ -1,0 +1,239 @@
+// wave_sort.hpp -- register-resident bitonic sort of 64*EPT floats by ONE 64-lane wavefront (gfx950).
+//
+// Element index e = lane*EPT + r (r = register index, the LOW bits), so that of the
+// log2(64*EPT)*(log2(64*EPT)+1)/2 compare-exchange stages only the 21 whose stride reaches across
+// lanes need a cross-lane move; every other stage is a v_min/v_max pair on two registers of the
+// same lane.  The network is the "flip" form of bitonic sort (first stage of every merge pairs e
+// with its mirror image inside the block, later stages pair e with e^stride): every
+// compare-exchange then sends the smaller key to the smaller index, so a cross-lane stage is
+//     x = med3(x, partner, lower ? -inf : +inf)        (one v_med3_f32)
+// with `lower` a per-lane constant of the stage.
+//
+// Cross-lane moves use the cheapest gfx950 mechanism per lane-xor mask:
+//   1, 2, 3 (quad_perm), 7 (row_half_mirror), 15 (row_mirror)  -> DPP v_mov  (VALU, no LDS port)
+//   4, 8, 16, 31                                                -> ds_swizzle (LDS crossbar, no memory)
+//   32, 63                                                      -> ds_bpermute
+// No LDS memory and no barrier is used: a wave sorts on its own.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace shw {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float as_f(int v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ int as_i(float v) { return __builtin_bit_cast(int, v); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  // mov_dpp leaves the "old" operand undefined: with row_mask = bank_mask = 0xf and a permutation
+  // that stays inside its row every lane is written, and the compiler emits no v_mov to seed it.
+  return as_f(__builtin_amdgcn_mov_dpp(as_i(x), CTRL, 0xf, 0xf, true));
+}
+
+// value of `x` held by lane (lane ^ MASK); every lane of the wave must be active.
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float x, int lane) {
+  if constexpr (MASK == 1) {
+    return dpp_mov<0xB1>(x);                       // quad_perm:[1,0,3,2]
+  } else if constexpr (MASK == 2) {
+    return dpp_mov<0x4E>(x);                       // quad_perm:[2,3,0,1]
+  } else if constexpr (MASK == 3) {
+    return dpp_mov<0x1B>(x);                       // quad_perm:[3,2,1,0]
+  } else if constexpr (MASK == 7) {
+    return dpp_mov<0x141>(x);                      // row_half_mirror
+  } else if constexpr (MASK == 15) {
+    return dpp_mov<0x140>(x);                      // row_mirror
+  } else if constexpr (MASK < 32) {
+    // ds_swizzle bit-mask mode: lane' = ((lane & and) | or) ^ xor inside each group of 32
+    return as_f(__builtin_amdgcn_ds_swizzle(as_i(x), (MASK << 10) | 0x1F));
+  } else {
+    return as_f(__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, as_i(x)));
+  }
+}
+
+__device__ __forceinline__ void cmp_swap(float& lo, float& hi) {
+  const float a = lo, b = hi;
+  lo = __builtin_fminf(a, b);
+  hi = __builtin_fmaxf(a, b);
+}
+
+// in-lane half-cleaner stages with strides J, J/2, ..., 1 (ascending, compile-time register pairs)
+template <int EPT, int J>
+__device__ __forceinline__ void lane_stages(float (&x)[EPT]) {
+  if constexpr (J >= 1) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      if ((r & J) == 0) cmp_swap(x[r], x[r | J]);
+    }
+    lane_stages<EPT, J / 2>(x);
+  }
+}
+
+// in-lane merges of size K = 2, 4, ..., EPT
+template <int EPT, int K>
+__device__ __forceinline__ void lane_merges(float (&x)[EPT]) {
+  if constexpr (K <= EPT) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int q = r ^ (K - 1);
+      if (q > r) cmp_swap(x[r], x[q]);
+    }
+    lane_stages<EPT, K / 4>(x);
+    lane_merges<EPT, K * 2>(x);
+  }
+}
+
+// cross-lane xor stages with lane masks M, M/2, ..., 1
+template <int EPT, int M>
+__device__ __forceinline__ void xlane_stages(float (&x)[EPT], int lane) {
+  if constexpr (M >= 1) {
+    const float bound = (lane & M) ? __builtin_inff() : -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      x[r] = __builtin_amdgcn_fmed3f(x[r], lane_xor<M>(x[r], lane), bound);
+    }
+    xlane_stages<EPT, M / 2>(x, lane);
+  }
+}
+
+// merges spanning 2^C lanes, C = 1 .. 6
+template <int EPT, int C>
+__device__ __forceinline__ void xlane_merges(float (&x)[EPT], int lane) {
+  if constexpr (C <= 6) {
+    constexpr int MASK = (1 << C) - 1;
+    const float bound = (lane & (1 << (C - 1))) ? __builtin_inff() : -__builtin_inff();
+    if constexpr (EPT == 1) {
+      x[0] = __builtin_amdgcn_fmed3f(x[0], lane_xor<MASK>(x[0], lane), bound);
+    } else {
+#pragma unroll
+      for (int r = 0; r < EPT / 2; ++r) {          // mirror pairs (r, EPT-1-r): two temporaries live
+        const float pa = lane_xor<MASK>(x[EPT - 1 - r], lane);
+        const float pb = lane_xor<MASK>(x[r], lane);
+        x[r] = __builtin_amdgcn_fmed3f(x[r], pa, bound);
+        x[EPT - 1 - r] = __builtin_amdgcn_fmed3f(x[EPT - 1 - r], pb, bound);
+      }
+    }
+    xlane_stages<EPT, (1 << C) / 4>(x, lane);
+    lane_stages<EPT, EPT / 2>(x);
+    xlane_merges<EPT, C + 1>(x, lane);
+  }
+}
+
+// ascending sort of the 64*EPT keys of a wave; sorted position of x[r] in lane `lane` is lane*EPT + r.
+template <int EPT>
+__device__ __forceinline__ void wave_sort(float (&x)[EPT], int lane) {
+  lane_merges<EPT, 2>(x);
+  xlane_merges<EPT, 1>(x, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Key + payload variant: items are 64-bit words (float key bits << 32 | original index).  Keys are
+// non-negative floats (circle coordinates, +inf padding), whose bit patterns order like unsigned
+// integers, and the index makes every item unique, so the result is the STABLE ascending order of
+// the keys (ties by original index) -- the order torch.sort yields in the reference (:163-164).
+// Compare-exchanges cost one v_cmp_*_u64 and two v_cndmask per 64-bit item instead of one
+// v_min/v_max/v_med3, which is why the loss-only kernels use the key-only network above.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned long long item_t;
+
+__device__ __forceinline__ item_t make_item(float key, int idx) {
+  return ((item_t)(unsigned)as_i(key) << 32) | (unsigned)idx;
+}
+__device__ __forceinline__ float item_key(item_t it) { return as_f((int)(it >> 32)); }
+__device__ __forceinline__ int item_idx(item_t it) { return (int)(unsigned)it; }
+
+template <int MASK>
+__device__ __forceinline__ item_t lane_xor_item(item_t x, int lane) {
+  const float lo = lane_xor<MASK>(as_f((int)(unsigned)x), lane);
+  const float hi = lane_xor<MASK>(as_f((int)(x >> 32)), lane);
+  return ((item_t)(unsigned)as_i(hi) << 32) | (unsigned)as_i(lo);
+}
+
+__device__ __forceinline__ void cmp_swap_item(item_t& lo, item_t& hi) {
+  const item_t a = lo, b = hi;
+  const bool sw = a > b;
+  lo = sw ? b : a;
+  hi = sw ? a : b;
+}
+
+template <int EPT, int J>
+__device__ __forceinline__ void lane_stages_kv(item_t (&x)[EPT]) {
+  if constexpr (J >= 1) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      if ((r & J) == 0) cmp_swap_item(x[r], x[r | J]);
+    }
+    lane_stages_kv<EPT, J / 2>(x);
+  }
+}
+
+template <int EPT, int K>
+__device__ __forceinline__ void lane_merges_kv(item_t (&x)[EPT]) {
+  if constexpr (K <= EPT) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int q = r ^ (K - 1);
+      if (q > r) cmp_swap_item(x[r], x[q]);
+    }
+    lane_stages_kv<EPT, K / 4>(x);
+    lane_merges_kv<EPT, K * 2>(x);
+  }
+}
+
+// keep own item or take the partner's: the lower lane keeps the smaller, the upper lane the larger
+__device__ __forceinline__ item_t pick_item(item_t own, item_t other, bool upper) {
+  const bool take = (other < own) != upper;       // items are unique: no tie case
+  return take ? other : own;
+}
+
+template <int EPT, int M>
+__device__ __forceinline__ void xlane_stages_kv(item_t (&x)[EPT], int lane) {
+  if constexpr (M >= 1) {
+    const bool upper = (lane & M) != 0;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) x[r] = pick_item(x[r], lane_xor_item<M>(x[r], lane), upper);
+    xlane_stages_kv<EPT, M / 2>(x, lane);
+  }
+}
+
+template <int EPT, int C>
+__device__ __forceinline__ void xlane_merges_kv(item_t (&x)[EPT], int lane) {
+  if constexpr (C <= 6) {
+    constexpr int MASK = (1 << C) - 1;
+    const bool upper = (lane & (1 << (C - 1))) != 0;
+    if constexpr (EPT == 1) {
+      x[0] = pick_item(x[0], lane_xor_item<MASK>(x[0], lane), upper);
+    } else {
+#pragma unroll
+      for (int r = 0; r < EPT / 2; ++r) {
+        const item_t pa = lane_xor_item<MASK>(x[EPT - 1 - r], lane);
+        const item_t pb = lane_xor_item<MASK>(x[r], lane);
+        x[r] = pick_item(x[r], pa, upper);
+        x[EPT - 1 - r] = pick_item(x[EPT - 1 - r], pb, upper);
+      }
+    }
+    xlane_stages_kv<EPT, (1 << C) / 4>(x, lane);
+    lane_stages_kv<EPT, EPT / 2>(x);
+    xlane_merges_kv<EPT, C + 1>(x, lane);
+  }
+}
+
+template <int EPT>
+__device__ __forceinline__ void wave_sort_kv(item_t (&x)[EPT], int lane) {
+  lane_merges_kv<EPT, 2>(x);
+  xlane_merges_kv<EPT, 1>(x, lane);
+}
+
+// ----- wave-wide sums (result valid in every lane) ---------------------------------------------
+__device__ __forceinline__ float wave_sum(float v, int lane) {
+  v += lane_xor<1>(v, lane);
+  v += lane_xor<2>(v, lane);
+  v += lane_xor<4>(v, lane);
+  v += lane_xor<8>(v, lane);
+  v += lane_xor<16>(v, lane);
+  v += lane_xor<32>(v, lane);
+  return v;
+}
+
+}  // namespace shw

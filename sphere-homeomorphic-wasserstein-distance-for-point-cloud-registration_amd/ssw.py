@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's spherical sliced-Wasserstein call shapes on top
+of the HIP C-ABI library.  Same names, argument order and return shapes as
+/root/reference/Point_Cloud_Resistration/losses/max_spherical_sliced_w.py (per pair) and
+max_spherical_sliced_w_fast.py (batched):
+
+    sliced_wasserstein_sphere(Xs, Xt, num_projections, device, u_weights=None, v_weights=None, p=2)  :289-310
+    sliced_wasserstein_sphere_fast(...)                                                      _fast.py:298-319
+    sliced_cost(Xs, Xt, Us, p=2, u_weights=None, v_weights=None)                 :251-286 / _fast.py:258-295
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every number is produced by
+the hand-written gfx950 kernels.  CPU tensors are rejected: there is no fallback path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_cloud(name, t):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the MI355X HIP path needs device tensors (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.shape[-1] != 3:
+        raise ValueError(f"{name} must have 3 coordinates per point, got shape {tuple(t.shape)}")
+
+
+def draw_directions(num_projections, device, batch=None, d=3):
+    """Uniform samples on the Stiefel manifold V_{d,2} from the GLOBAL torch generator, consumed exactly
+    like the reference (randn of (L,d,2) resp. (B,L,d,2) on `device`, then reduced QR; :307-308,
+    _fast.py:317-318)."""
+    shape = (num_projections, d, 2) if batch is None else (batch, num_projections, d, 2)
+    Z = torch.randn(shape, device=device)
+    U, _ = torch.linalg.qr(Z)
+    return U
+
+
+class _PairLosses(torch.autograd.Function):
+    """(B,n,3), (B,m,3), dirs -> (B,) per-pair mean over slices of the circular OT cost W_p^p."""
+
+    @staticmethod
+    def forward(ctx, Xs, Xt, Us, p, shared_dirs):
+        lib = _lib.load()
+        B, n, _ = Xs.shape
+        m = Xt.shape[1]
+        L = Us.shape[-3]
+        dev = Xs.device
+        Xs_c, Xt_c, Us_c = Xs.contiguous(), Xt.contiguous(), Us.contiguous()
+        stride = 0 if shared_dirs else L * 6
+        slice_cost = torch.empty(B * L, dtype=torch.float32, device=dev)
+        slice_shift = torch.empty(B * L, dtype=torch.int32, device=dev)
+        pair_loss = torch.empty(B, dtype=torch.float32, device=dev)
+        need_grad = Xs.requires_grad or Xt.requires_grad
+        stream = _stream_ptr(dev)
+        with torch.cuda.device(dev):
+            if need_grad:
+                coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev)
+                coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev)
+                _lib.check(lib.shw_ssw_forward_grad(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), B, n, m, L,
+                                                    stride, float(p), slice_cost.data_ptr(), slice_shift.data_ptr(),
+                                                    coef_s.data_ptr(), coef_t.data_ptr(), stream),
+                           "shw_ssw_forward_grad")
+                ctx.save_for_backward(Xs_c, Xt_c, Us_c, coef_s, coef_t)
+                ctx.dims = (B, n, m, L, stride)
+            else:
+                _lib.check(lib.shw_ssw_forward(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), B, n, m, L, stride,
+                                               float(p), slice_cost.data_ptr(), slice_shift.data_ptr(), stream),
+                           "shw_ssw_forward")
+            _lib.check(lib.shw_ssw_reduce(slice_cost.data_ptr(), B, L, 1.0 / L, pair_loss.data_ptr(), None, stream),
+                       "shw_ssw_reduce")
+        cost2d, shift2d = slice_cost.view(B, L), slice_shift.view(B, L)
+        ctx.mark_non_differentiable(cost2d, shift2d)
+        return pair_loss, cost2d, shift2d
+
+    @staticmethod
+    def backward(ctx, g_pair, _g_cost, _g_shift):
+        lib = _lib.load()
+        Xs_c, Xt_c, Us_c, coef_s, coef_t = ctx.saved_tensors
+        B, n, m, L, stride = ctx.dims
+        dev = Xs_c.device
+        gxs = torch.empty_like(Xs_c)
+        gxt = torch.empty_like(Xt_c)
+        with torch.cuda.device(dev):
+            _lib.check(lib.shw_ssw_backward_points(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(),
+                                                   coef_s.data_ptr(), coef_t.data_ptr(), B, n, m, L, stride,
+                                                   1.0 / L, gxs.data_ptr(), gxt.data_ptr(), _stream_ptr(dev)),
+                       "shw_ssw_backward_points")
+        w = g_pair.to(torch.float32).view(B, 1, 1)
+        return gxs * w, gxt * w, None, None, None
+
+
+def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False):
+    """Core op: batched clouds (B,n,3), (B,m,3); directions (B,L,3,2) or shared (L,3,2).
+    Returns (B,) per-pair losses = mean over slices of W_p^p on the slice circle
+    [optionally also the (B,L) per-slice costs and optimal shifts]."""
+    _check_cloud("Xs", Xs)
+    _check_cloud("Xt", Xt)
+    _check_cloud_dirs(Us)
+    if Xs.dim() != 3 or Xt.dim() != 3 or Xs.shape[0] != Xt.shape[0]:
+        raise ValueError("Xs and Xt must be (B,n,3) and (B,m,3) with the same B")
+    shared = Us.dim() == 3
+    if not shared and Us.shape[0] != Xs.shape[0]:
+        raise ValueError("per-pair directions must be (B,L,3,2)")
+    if not (float(p) >= 1.0):
+        raise ValueError("p must be >= 1")
+    pair, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared)
+    if return_slices:
+        return pair, cost, shift
+    return pair
+
+
+def _check_cloud_dirs(Us):
+    if not isinstance(Us, torch.Tensor) or not Us.is_cuda or Us.dtype != torch.float32:
+        raise TypeError("Us must be a float32 device tensor")
+    if Us.dim() not in (3, 4) or tuple(Us.shape[-2:]) != (3, 2):
+        raise ValueError(f"Us must be (L,3,2) or (B,L,3,2), got {tuple(Us.shape)}")
+
+
+def _reject_weights(u_weights, v_weights):
+    if u_weights is not None or v_weights is not None:
+        raise NotImplementedError(
+            "non-uniform u_weights / v_weights are not implemented in the HIP path yet "
+            "(SURVEY.md 8f rank 1); refusing to fall back to a CPU path")
+
+
+def sliced_cost(Xs, Xt, Us, p=2, u_weights=None, v_weights=None):
+    """Reference `sliced_cost`.  Per pair -- Xs (n,3), Xt (m,3), Us (L,3,2) -> 0-dim tensor, the mean
+    over slices (:286).  Batched -- Xs (B,n,3), Xt (B,m,3), Us (B,L,3,2) -> shape-[1] tensor, the SUM
+    over pairs of the per-pair means (_fast.py:291-293).  Batched p == 1, which raises in the
+    reference, is evaluated pair-wise here (documented extension)."""
+    _reject_weights(u_weights, v_weights)
+    if Xs.dim() == 2:
+        pair = ssw_pair_losses(Xs.unsqueeze(0), Xt.unsqueeze(0), Us, p)
+        return pair[0]
+    pair = ssw_pair_losses(Xs, Xt, Us, p)
+    return pair.sum().reshape(1)
+
+
+def sliced_wasserstein_sphere(Xs, Xt, num_projections, device, u_weights=None, v_weights=None, p=2):
+    """Reference signature (:289).  Xs (n,3), Xt (m,3) on `device` -> 0-dim tensor."""
+    U = draw_directions(num_projections, device, d=Xs.shape[1])
+    return sliced_cost(Xs, Xt, U, p=p, u_weights=u_weights, v_weights=v_weights)
+
+
+def sliced_wasserstein_sphere_fast(Xs, Xt, num_projections, device, u_weights=None, v_weights=None, p=2):
+    """Reference batched signature (_fast.py:298).  Xs (B,n,3), Xt (B,m,3) -> shape-[1] tensor."""
+    U = draw_directions(num_projections, device, batch=Xs.shape[0], d=Xs.shape[2])
+    return sliced_cost(Xs, Xt, U, p=p, u_weights=u_weights, v_weights=v_weights)
