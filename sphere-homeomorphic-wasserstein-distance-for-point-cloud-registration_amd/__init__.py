@@ -2,10 +2,13 @@
 
 Importable as `importlib.import_module("sphere-homeomorphic-wasserstein-distance-for-point-cloud-registration_amd")`
 or through the top-level alias module `shw_amd`."""
-from . import _lib
+from . import _lib, dist
 from .chamfer import chamfer_distance, chamfer_pair_losses
+from .modules import (ChamferCriterion, SlicedSphereW, SSWCriterion, max_spherical_wassersten_distance,
+                      max_spherical_wassersten_distance_fast)
 from .ssw import (draw_directions, sliced_cost, sliced_wasserstein_sphere, sliced_wasserstein_sphere_fast,
                   ssw_pair_losses)
 
-__all__ = ["_lib", "chamfer_distance", "chamfer_pair_losses", "draw_directions", "sliced_cost", "sliced_wasserstein_sphere", "sliced_wasserstein_sphere_fast",
+__all__ = ["_lib", "dist", "ChamferCriterion", "SlicedSphereW", "SSWCriterion",
+           "max_spherical_wassersten_distance", "max_spherical_wassersten_distance_fast", "chamfer_distance", "chamfer_pair_losses", "draw_directions", "sliced_cost", "sliced_wasserstein_sphere", "sliced_wasserstein_sphere_fast",
            "ssw_pair_losses"]

@@ -1,0 +1,113 @@
+"""Module-level call shapes of the reference, host-side Python over the HIP op:
+
+* `SlicedSphereW` -- drop-in for the `CSW` slot that train_W_COS.py:393 / train_Pseudo_W_COS.py:391 fill with
+  `Cos_disimilarity_W(device, p)` (s2_wasserstein.py:13-66): ctor `(device, p)`, call `CSW(x, y) -> scalar`,
+  x (B,N,3) or (N,3); batch-MEAN of the per-pair distance ** (1/p) (s2_wasserstein.py:41-48).
+* `max_spherical_wassersten_distance` / `_fast` -- the adversarial phi-max wrappers
+  (max_spherical_sliced_w.py:498-536, _fast.py:346-380): `forward(first, second, train_or_test) ->
+  (ssw, phi(first), phi(second))`.
+* `SSWCriterion` / `ChamferCriterion` -- the trainer-level `criteria(template, transformed_source, ...)`
+  slots (train_W_COS.py:133,171; train_CD.py:123,161).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .chamfer import chamfer_distance
+from .ssw import draw_directions, sliced_wasserstein_sphere, sliced_wasserstein_sphere_fast, ssw_pair_losses
+
+
+class SlicedSphereW(nn.Module):
+    """`CSW`-slot module backed by the spherical sliced-Wasserstein HIP op."""
+
+    def __init__(self, device, p=2, num_projections=512):
+        super().__init__()
+        self.device = device
+        self.p = p
+        self.num_projections = num_projections
+
+    def forward(self, x, y):
+        if x.dim() == 2:
+            x, y = x.unsqueeze(0), y.unsqueeze(0)
+        B = x.shape[0]
+        U = draw_directions(self.num_projections, x.device, batch=B, d=x.shape[-1])
+        pair = ssw_pair_losses(x, y, U, self.p)
+        if B >= 2:
+            return torch.pow(pair, 1.0 / self.p).sum() / int(B)      # s2_wasserstein.py:41-45
+        return torch.pow(pair[0], 1.0 / self.p)                        # :47-48
+
+
+def _sum_over_pairs(SSW, first, second, num_projections, device, p):
+    """`ssw = sum_i SSW(first[i], second[i], ...)` (:518-519).  When SSW is this package's own per-pair
+    function the B direction sets are drawn in the same order (same generator consumption) and the B pairs
+    are evaluated by ONE batched launch instead of B."""
+    if SSW is sliced_wasserstein_sphere:
+        U = torch.stack([draw_directions(num_projections, device, d=first.shape[-1]) for _ in range(first.shape[0])])
+        return ssw_pair_losses(first, second, U, p).sum()
+    ssw = 0
+    for i in range(len(first)):
+        ssw = ssw + SSW(first[i], second[i], num_projections, device, p=p)
+    return ssw
+
+
+class max_spherical_wassersten_distance(nn.Module):
+    """phi-max wrapper, per-pair SSW (max_spherical_sliced_w.py:498-536)."""
+
+    def __init__(self, num_projections, phi, SSW, phi_op, p=2, max_iter=10, device="cuda", verbose=False):
+        super().__init__()
+        self.num_projections, self.phi, self.SSW, self.phi_op = num_projections, phi, SSW, phi_op
+        self.p, self.max_iter, self.device, self.verbose = p, max_iter, device, verbose
+
+    def _ssw(self, a, b):
+        return _sum_over_pairs(self.SSW, a, b, self.num_projections, self.device, self.p)
+
+    def forward(self, first_samples, second_samples, train_or_test="train"):
+        first_detach, second_detach = first_samples.detach(), second_samples.detach()
+        if train_or_test == "train":
+            for _ in range(self.max_iter):
+                ssw = self._ssw(self.phi(first_detach), self.phi(second_detach))
+                loss = -ssw                                   # gradient ascent on phi (:521)
+                self.phi_op.zero_grad()
+                loss.backward(retain_graph=True)
+                self.phi_op.step()
+                if self.verbose:
+                    print(ssw.item())
+        elif train_or_test != "test":
+            raise ValueError("train_or_test must be 'train' or 'test'")
+        first_t, second_t = self.phi(first_samples), self.phi(second_samples)
+        return self._ssw(first_t, second_t), first_t, second_t
+
+
+class max_spherical_wassersten_distance_fast(max_spherical_wassersten_distance):
+    """phi-max wrapper, batched SSW (_fast.py:346-380)."""
+
+    def _ssw(self, a, b):
+        return self.SSW(a, b, self.num_projections, self.device, p=self.p)
+
+
+class SSWCriterion(nn.Module):
+    """Trainer-level slot of train_W_COS.py:133,171: `criteria(template, transformed_source,
+    train_or_test=...) -> (loss, phi(template), phi(source))` with the sliced loss in the CSW position and an
+    optional sphere map phi (identity when None)."""
+
+    def __init__(self, device, p=2, num_projections=512, phi=None):
+        super().__init__()
+        self.csw = SlicedSphereW(device, p, num_projections)
+        self.phi = phi
+
+    def forward(self, template, source, train_or_test="train"):
+        a = template if self.phi is None else self.phi(template)
+        b = source if self.phi is None else self.phi(source)
+        return self.csw(a, b), a, b
+
+
+class ChamferCriterion(nn.Module):
+    """train_CD.py:123,161: `criteria(template, transformed_source)[0]`."""
+
+    def forward(self, template, source, batch_reduction="mean"):
+        return chamfer_distance(template, source, batch_reduction=batch_reduction)
+
+
+__all__ = ["SlicedSphereW", "max_spherical_wassersten_distance", "max_spherical_wassersten_distance_fast",
+           "SSWCriterion", "ChamferCriterion", "sliced_wasserstein_sphere", "sliced_wasserstein_sphere_fast"]

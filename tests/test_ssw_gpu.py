@@ -388,3 +388,51 @@ def test_chamfer_against_numpy_oracle(shw, n, m):
     (dmat.min(2).values.mean(1) + dmat.min(1).values.mean(1)).mean().backward()
     assert np.abs(xs.grad.cpu().numpy() - xd.grad.numpy()).max() < 1e-4 * np.abs(xd.grad.numpy()).max()
     assert np.abs(ys.grad.cpu().numpy() - yd.grad.numpy()).max() < 1e-4 * np.abs(yd.grad.numpy()).max()
+
+
+# ------------------------------------------------------------------------------ module-level call shapes (8b)
+def test_csw_slot_module_and_criteria(shw):
+    g = torch.Generator().manual_seed(12)
+    x, y = unit_cloud(g, 4, 256).cuda().requires_grad_(True), unit_cloud(g, 4, 256).cuda()
+    csw = shw.SlicedSphereW("cuda", p=2, num_projections=32)
+    torch.manual_seed(3)
+    val = csw(x, y)
+    assert val.dim() == 0
+    torch.manual_seed(3)
+    U = shw.draw_directions(32, "cuda", batch=4)
+    expect = shw.ssw_pair_losses(x.detach(), y, U, 2).sqrt().mean()
+    assert abs(val.item() - expect.item()) < 1e-6 * expect.item()
+    val.backward()
+    assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
+    single = csw(x[0].detach(), y[0])
+    assert single.dim() == 0
+    loss, a, b = shw.SSWCriterion("cuda", 2, 16)(x.detach(), y, train_or_test="test")
+    assert loss.dim() == 0 and a.shape == x.shape and b.shape == y.shape
+    cd = shw.ChamferCriterion()(x.detach(), y)[0]
+    assert cd.dim() == 0
+
+
+def test_phi_max_wrappers_run_and_ascend(shw):
+    g = torch.Generator().manual_seed(13)
+    x, y = torch.randn(4, 128, 3, generator=g).cuda(), torch.randn(4, 128, 3, generator=g).cuda()
+
+    class Sphere(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3, 3)
+
+        def forward(self, t):
+            return torch.nn.functional.normalize(self.lin(t), dim=-1)
+
+    torch.manual_seed(0)
+    for cls, fn in ((shw.max_spherical_wassersten_distance, shw.sliced_wasserstein_sphere),
+                    (shw.max_spherical_wassersten_distance_fast, shw.sliced_wasserstein_sphere_fast)):
+        phi = Sphere().cuda()
+        op = torch.optim.Adam(phi.parameters(), lr=1e-2)
+        wrap = cls(16, phi, fn, op, p=2, max_iter=3, device="cuda")
+        before = [q.detach().clone() for q in phi.parameters()]
+        ssw, a, b = wrap(x, y, train_or_test="train")
+        assert torch.isfinite(ssw).all() and a.shape == x.shape and b.shape == y.shape
+        assert any((q.detach() - q0).abs().max() > 0 for q, q0 in zip(phi.parameters(), before))
+        ssw_t, _, _ = wrap(x, y, train_or_test="test")
+        assert torch.isfinite(ssw_t).all()
