@@ -5,19 +5,28 @@
 namespace shw {
 
 // ---------------------------------------------------------------------------------------------
-// reductions: per-pair scaled sum over slices, then total over pairs.  Fixed order, no atomics.
+// reductions: per-pair scaled sum over slices, then total over pairs.  Fixed order, no atomics:
+// one wavefront per pair, lane j adds slices j, j+64, ... in order, then a butterfly over the lanes.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ssw_reduce_pairs_kernel(const float* __restrict__ slice_cost, int slices,
-                                                               float scale, float* __restrict__ pair_loss) {
-  __shared__ float part[4];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ float pair_sum(const float* __restrict__ row, int slices, int lane) {
   float acc = 0.f;
-  for (int l = threadIdx.x; l < slices; l += 256) acc += slice_cost[(long)b * slices + l];
-  acc = wave_sum(acc, lane);
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) pair_loss[b] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+  int l = lane;
+  for (; l + 192 < slices; l += 256) {             // four independent loads in flight
+    const float a = row[l], b = row[l + 64], c = row[l + 128], d = row[l + 192];
+    acc += a; acc += b; acc += c; acc += d;
+  }
+  for (; l < slices; l += 64) acc += row[l];
+  return wave_sum(acc, lane);
+}
+
+__global__ __launch_bounds__(256) void ssw_reduce_pairs_kernel(const float* __restrict__ slice_cost, int pairs,
+                                                               int slices, float scale,
+                                                               float* __restrict__ pair_loss) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= pairs) return;
+  const float v = pair_sum(slice_cost + (long)b * slices, slices, lane) * scale;
+  if (lane == 0) pair_loss[b] = v;
 }
 
 __global__ __launch_bounds__(64) void ssw_reduce_total_kernel(const float* __restrict__ pair_loss, int pairs,
@@ -29,6 +38,31 @@ __global__ __launch_bounds__(64) void ssw_reduce_total_kernel(const float* __res
   if (lane == 0) {
     total[0] = acc;
     total[1] = acc / (float)pairs;
+  }
+}
+
+// Both reductions in ONE launch for small batches (pairs <= 256): the 16 waves of a single workgroup
+// take pairs w, w+16, ...; after the barrier wave 0 adds the pair losses exactly like
+// ssw_reduce_total_kernel.  Same arithmetic order as the two-kernel form, one kernel boundary less.
+__global__ __launch_bounds__(1024) void ssw_reduce_fused_kernel(const float* __restrict__ slice_cost, int pairs,
+                                                                int slices, float scale,
+                                                                float* __restrict__ pair_loss,
+                                                                float* __restrict__ total) {
+  __shared__ float pl[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < pairs; b += 16) {
+    const float v = pair_sum(slice_cost + (long)b * slices, slices, lane) * scale;
+    if (lane == 0) { pair_loss[b] = v; pl[b] = v; }
+  }
+  __syncthreads();
+  if (wave == 0 && total) {
+    float acc = 0.f;
+    for (int b = lane; b < pairs; b += 64) acc += pl[b];
+    acc = wave_sum(acc, lane);
+    if (lane == 0) {
+      total[0] = acc;
+      total[1] = acc / (float)pairs;
+    }
   }
 }
 
@@ -59,8 +93,13 @@ int shw_ssw_reduce(const float* slice_cost, int pairs, int slices, float scale, 
                    void* stream) {
   if (!slice_cost || !pair_loss || pairs < 0 || slices < 0) return (int)hipErrorInvalidValue;
   if (pairs == 0) return 0;
-  hipLaunchKernelGGL(shw::ssw_reduce_pairs_kernel, dim3(pairs), dim3(256), 0, (hipStream_t)stream, slice_cost, slices,
-                     scale, pair_loss);
+  if (pairs <= 256) {
+    hipLaunchKernelGGL(shw::ssw_reduce_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, slice_cost, pairs,
+                       slices, scale, pair_loss, total);
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL(shw::ssw_reduce_pairs_kernel, dim3((pairs + 3) / 4), dim3(256), 0, (hipStream_t)stream, slice_cost,
+                     pairs, slices, scale, pair_loss);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   if (total) {

@@ -10,7 +10,8 @@ constexpr int min_waves_per_simd(int ept, int pmode) {
   return ept <= 16 ? (pmode == 2 ? 6 : 4) : (ept == 32 ? (pmode == 2 ? 5 : 3) : 1);
 }
 
-template <int EPT, int WAVES, int PMODE>
+// FULL: n == m == 64*EPT (no padding atoms): mask-free projection and the fast shift evaluation.
+template <int EPT, int WAVES, int PMODE, bool FULL>
 __global__ __launch_bounds__(WAVES * 64, min_waves_per_simd(EPT, PMODE)) void ssw_forward_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves_per_simd(EPT, PMODE)) void ss
     // constants of the sort (and the point offsets) out of this loop and holding them in VGPRs.
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const float part = load_coords<EPT>(X, count, ln, U, key);
+    const float part = load_coords<EPT, FULL>(X, count, ln, U, key);
     wave_sort<EPT>(key, ln);
     if (which == 0) {
       sum_v = wave_sum(part, lane);
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves_per_simd(EPT, PMODE)) void ss
   __builtin_amdgcn_wave_barrier();
 
   float best;
-  const int k = solve_shift<EPT, PMODE>(key, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
+  const int k = solve_shift<EPT, PMODE, FULL>(key, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
   if (lane == 0) {
     A.slice_cost[s] = best / (float)A.n;
     if (A.slice_shift) A.slice_shift[s] = k;
@@ -64,10 +65,14 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
   if (groups > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)groups;
   const size_t lds = (size_t)WAVES * EPT * kWave * sizeof(float);
+  const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
+  const dim3 grid((unsigned)groups), block(WAVES * 64);
   if (A.p_int == 2) {
-    hipLaunchKernelGGL((ssw_forward_kernel<EPT, WAVES, 2>), dim3((unsigned)groups), dim3(WAVES * 64), lds, stream, A);
+    if (full) hipLaunchKernelGGL((ssw_forward_kernel<EPT, WAVES, 2, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_kernel<EPT, WAVES, 2, false>), grid, block, lds, stream, A);
   } else {
-    hipLaunchKernelGGL((ssw_forward_kernel<EPT, WAVES, 0>), dim3((unsigned)groups), dim3(WAVES * 64), lds, stream, A);
+    if (full) hipLaunchKernelGGL((ssw_forward_kernel<EPT, WAVES, 0, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_kernel<EPT, WAVES, 0, false>), grid, block, lds, stream, A);
   }
   return (int)hipGetLastError();
 }

@@ -167,27 +167,82 @@ __device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float*
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  cm = wave_sum(sm, lane);
-  c0 = wave_sum(s0, lane);
-  cp = wave_sum(sp, lane);
+  cm = wave_sum_uniform(sm, lane);
+  c0 = wave_sum_uniform(s0, lane);
+  cp = wave_sum_uniform(sp, lane);
+}
+
+// Fast form of shift_costs3 for n == 64*EPT exactly (every register slot is a real atom, n a power of
+// two).  With base = k-1 = kh*EPT + kl (0 <= kl < EPT) the window position j of lane l is sorted
+// position (l + kh + c)*EPT + row with  row = (kl + j) mod EPT  and carry  c = (kl + j) div EPT in
+// {0,1,2}: row and c are WAVE-UNIFORM, so each fetch is  ds_read(addr_c + row*256) + turn_c  with the
+// three per-lane (address, turn) pairs prepared once per evaluation -- 4 VALU per fetch instead of ~15.
+template <int EPT, int PMODE>
+__device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const float* vbuf, int lane, int k,
+                                                  float p, int p_int, float& cm, float& c0, float& cp) {
+  constexpr int LOG = __builtin_ctz(EPT);
+  const int base = k - 1;
+  const int kl = base & (EPT - 1);
+  const int kh = base >> LOG;                                   // floor division (arithmetic shift)
+  int addr[3];
+  float turn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = lane + kh + c;                              // unwrapped lane index of the atom
+    addr[c] = (col & 63) << 2;                                  // byte offset inside an LDS row
+    turn[c] = (float)(col >> 6);                                // whole turns around the circle
+  }
+  const char* rows = reinterpret_cast<const char*>(vbuf);
+  auto fetch = [&](int j) -> float {                            // j compile-time after unrolling
+    const int rj = kl + j;                                      // scalar
+    const int row = rj & (EPT - 1);
+    const bool carry = (j < EPT) ? (rj >= EPT) : (rj >= 2 * EPT);
+    const int a = (j < EPT) ? (carry ? addr[1] : addr[0]) : (carry ? addr[2] : addr[1]);
+    const float t = (j < EPT) ? (carry ? turn[1] : turn[0]) : (carry ? turn[2] : turn[1]);
+    return *reinterpret_cast<const float*>(rows + a + (row << 8)) + t;
+  };
+  float sm = 0.f, s0 = 0.f, sp = 0.f;
+  float prev = fetch(0), cur = fetch(1);
+  constexpr int CH = EPT < 8 ? EPT : 8;
+#pragma unroll
+  for (int r0 = 0; r0 < EPT; r0 += CH) {
+    float nxt[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) nxt[j] = fetch(r0 + j + 2);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      sm += pow_abs<PMODE>(u[r0 + j] - prev, p, p_int);
+      s0 += pow_abs<PMODE>(u[r0 + j] - cur, p, p_int);
+      sp += pow_abs<PMODE>(u[r0 + j] - nxt[j], p, p_int);
+      prev = cur;
+      cur = nxt[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cm = wave_sum_uniform(sm, lane);
+  c0 = wave_sum_uniform(s0, lane);
+  cp = wave_sum_uniform(sp, lane);
 }
 
 // Minimise the convex sequence c(k), |k| <= n (theta in [-1, 1], the reference's bracket :174-177).
 // Returns k*, writes c(k*) (sum form).
-template <int EPT, int PMODE>
+template <int EPT, int PMODE, bool FULL = false>
 __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* vbuf, int lane, int n,
                                            float sum_u, float sum_v, float p, int p_int, float& best) {
   int lo = -n, hi = n;
   float guess = rintf(sum_u - sum_v);
   guess = fminf(fmaxf(guess, (float)lo), (float)hi);
-  int k = __builtin_amdgcn_readfirstlane((int)guess);
+  int k = __builtin_amdgcn_readfirstlane((int)guess);         // k lives in an SGPR from here on
   bool lo_tight = false, hi_tight = false;
   int step = 1;
   float cm, c0, cp;
   // every iteration removes k from [lo, hi]; galloping doubles, bisection halves: <= ~2 log2(2n)+2
   // iterations.  The hard cap only guards against non-finite input (comparisons all false -> exit).
   for (int it = 0; it < 64; ++it) {
-    shift_costs3<EPT, PMODE>(u, vbuf, lane, n, k, p, p_int, cm, c0, cp);
+    int ln = lane;                       // opaque copy: no lane-derived constants held across iterations
+    asm volatile("" : "+v"(ln));
+    if constexpr (FULL) shift_costs3_full<EPT, PMODE>(u, vbuf, ln, k, p, p_int, cm, c0, cp);
+    else shift_costs3<EPT, PMODE>(u, vbuf, ln, n, k, p, p_int, cm, c0, cp);
     const bool right = (cp < c0) && (k < hi);
     const bool left = !right && (cm < c0) && (k > lo);
     if (!right && !left) break;
@@ -210,7 +265,7 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
 
 // Project the cloud onto the slice's circle: lane owns points r*64 + lane (coalesced 12-byte
 // records).  Padding keys are +inf so that they sort behind every real coordinate.
-template <int EPT>
+template <int EPT, bool FULL = false>
 __device__ __forceinline__ float load_coords(const float* __restrict__ X, int count, int lane,
                                              const float (&U)[6], float (&key)[EPT]) {
   float acc = 0.f;
@@ -220,19 +275,21 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
     float px[CH], py[CH], pz[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int i = min((r0 + j) * kWave + lane, count - 1);   // clamp: branch-free, always in bounds
+      const int raw = (r0 + j) * kWave + lane;
+      const int i = FULL ? raw : min(raw, count - 1);           // clamp: branch-free, always in bounds
       px[j] = X[3 * i]; py[j] = X[3 * i + 1]; pz[j] = X[3 * i + 2];
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const int i = (r0 + j) * kWave + lane;
-      // "+ 0.f": a sum that starts from +0 like the reference's matmul accumulator (:270), so that an
+      // fma(x, u, +0): a sum that starts from +0 like the reference's matmul accumulator (:270), so that an
       // all-zero point projects to (+0, +0) -- never -0 -- and lands on coordinate 0 (G4 fixture)
-      const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], px[j] * U[0])) + 0.f;
-      const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], px[j] * U[1])) + 0.f;
+      const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
+      const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], fmaf(px[j], U[1], 0.f)));
       const float c = circle_coord(a, b);
-      acc += (i < count) ? c : 0.f;
-      key[r0 + j] = (i < count) ? c : __builtin_inff();
+      const bool live = FULL || (i < count);
+      acc += live ? c : 0.f;
+      key[r0 + j] = live ? c : __builtin_inff();
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -32,9 +32,16 @@ __device__ __forceinline__ float dpp_mov(float x) {
 }
 
 // value of `x` held by lane (lane ^ MASK); every lane of the wave must be active.
+#ifndef SHW_XLANE_DPP
+#define SHW_XLANE_DPP 0   // 0: every cross-lane move on the LDS crossbar (ds_swizzle / ds_bpermute);
+#endif                    // 1: DPP v_mov for the masks DPP can express.  Measured on MI355X: the kernels
+                          // are VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 100 %) with the LDS pipe < 10 %
+                          // busy, so moving the 13 DPP stages to ds_swizzle removes ~9 % of the VALU work.
 template <int MASK>
 __device__ __forceinline__ float lane_xor(float x, int lane) {
-  if constexpr (MASK == 1) {
+  if constexpr (SHW_XLANE_DPP == 0 && MASK < 32) {
+    return as_f(__builtin_amdgcn_ds_swizzle(as_i(x), (MASK << 10) | 0x1F));
+  } else if constexpr (MASK == 1) {
     return dpp_mov<0xB1>(x);                       // quad_perm:[1,0,3,2]
   } else if constexpr (MASK == 2) {
     return dpp_mov<0x4E>(x);                       // quad_perm:[2,3,0,1]
@@ -234,6 +241,13 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
   v += lane_xor<16>(v, lane);
   v += lane_xor<32>(v, lane);
   return v;
+}
+
+// same, but the result is handed back through an SGPR so that the compiler's divergence analysis
+// knows it is wave-uniform (branches on it become scalar branches, values derived from it stay in
+// SGPRs instead of being recomputed per lane)
+__device__ __forceinline__ float wave_sum_uniform(float v, int lane) {
+  return as_f(__builtin_amdgcn_readfirstlane(as_i(wave_sum(v, lane))));
 }
 
 }  // namespace shw

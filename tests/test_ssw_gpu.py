@@ -436,3 +436,21 @@ def test_phi_max_wrappers_run_and_ascend(shw):
         assert any((q.detach() - q0).abs().max() > 0 for q, q0 in zip(phi.parameters(), before))
         ssw_t, _, _ = wrap(x, y, train_or_test="test")
         assert torch.isfinite(ssw_t).all()
+
+
+def test_reduce_paths_agree_and_match_torch(shw):
+    """C-ABI reduction: the fused (pairs <= 256) and the two-kernel (pairs > 256) forms use the same summation
+    order; both agree with a float64 sum to fp32 rounding."""
+    lib = shw._lib.load()
+    g = torch.Generator().manual_seed(8)
+    for pairs, slices in ((1, 1), (3, 70), (64, 512), (256, 33), (300, 129)):
+        cost = torch.rand(pairs, slices, generator=g).cuda()
+        pl = torch.empty(pairs, device="cuda")
+        tot = torch.empty(2, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        shw._lib.check(lib.shw_ssw_reduce(cost.data_ptr(), pairs, slices, 1.0 / slices, pl.data_ptr(),
+                                          tot.data_ptr(), st), "reduce")
+        ref = cost.double().mean(1)
+        assert torch.allclose(pl.double(), ref, rtol=1e-6)
+        assert abs(tot[0].item() - ref.sum().item()) < 2e-6 * ref.sum().item()
+        assert abs(tot[1].item() - ref.mean().item()) < 2e-6 * ref.mean().item()
