@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--slices", type=int, default=512)
     ap.add_argument("--p", type=float, default=2.0)
+    ap.add_argument("--mode", default="forward", choices=["forward", "train", "chamfer"],
+                    help="forward: loss evaluation (the headline metric); train: loss + input gradients through "
+                         "the Python mirror's autograd Function; chamfer: Chamfer baseline forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a hipGraph instead of launching eagerly (measured on MI355X: eager "
@@ -87,6 +90,9 @@ def main():
     slice_shift = torch.empty(B * L, dtype=torch.int32, device=device)
     pair_loss = torch.empty(B, dtype=torch.float32, device=device)
     total = torch.empty(2, dtype=torch.float32, device=device)
+
+    if args.mode != "forward":
+        return side_modes(args, shw_amd, x, y, U, device, rank)
 
     def enqueue_loss():
         """The hot path: every kernel of one loss evaluation, enqueued on torch's current HIP stream."""
@@ -177,11 +183,19 @@ def main():
         # clouds read once + directions + per-pair loss
         algo_bytes = 12 * B * (N + N) + 24 * B * L + 4 * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = os.environ.get("SHW_BENCH_TRAFFIC_BYTES")   # filled in from a rocprofv3 --pmc pass when available
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json: FETCH_SIZE
+        # doubled per the gfx950 correction + WRITE_SIZE); only valid for the workload it was measured on
+        traffic = os.environ.get("SHW_BENCH_TRAFFIC_BYTES")
+        if traffic is None and (B, N, L, p) == (64, 2048, 512, 2.0):
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                    traffic = json.load(fh)["ssw_forward_kernel<32,4,2,true>"]["traffic_bytes"]
+            except Exception:
+                traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": float(traffic) if traffic else None,
-            "kernel": "ssw_forward_kernel<32,4,2>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
+            "kernel": "ssw_forward_kernel<32,4,2,true>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
             "note": "compulsory HBM traffic is 0.06 B/point-pair: the kernel is VALU/LDS-crossbar bound (in-register "
                     "bitonic sort), not HBM bound; see DESIGN.md for the compare-exchange model",
             "point_pairs_per_s_kernel_only": B * N * L / (kernel_ms * 1e-3),
@@ -193,6 +207,35 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def side_modes(args, shw, x, y, U, device, rank):
+    """Secondary measurements (not the headline line): training step and Chamfer baseline, single GPU."""
+    B, N, L, p = args.batch, args.points, args.slices, args.p
+    if args.mode == "train":
+        xs = x.clone().requires_grad_(True)
+        ys = y.clone().requires_grad_(True)
+
+        def step():
+            xs.grad = None
+            ys.grad = None
+            shw.sliced_cost(xs, ys, U, p=p).backward()
+        unit, per_step = "point-pairs/s (forward + input gradients)", B * N * L
+    else:
+        def step():
+            shw.chamfer_distance(x, y)
+        unit, per_step = "pair-distances/s (both directions)", 2 * B * N * N
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    el = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"metric": args.mode, "value": per_step / el, "unit": unit, "ms_per_step": 1e3 * el,
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
+                      "config": {"workload": "B=%d N=%d L=%d p=%g" % (B, N, L, p)}}), flush=True)
 
 
 def cpu_baseline(x, y, U, p, sample_pairs):

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline $@"
+ARGS="--steps 30 --warmup 20 --no-cpu-baseline $@"
 cd $ROOT
 echo "== kernel trace" 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || { echo trace failed; tail -20 $OUT/trace.log; exit 1; }
