@@ -1,4 +1,6 @@
 // shw_ssw_fwd.hip -- loss-only kernel for p != 1 (key-only register sort).  See ssw_common.hpp.
+#include <cstdlib>
+
 #include "ssw_common.hpp"
 
 namespace shw {
@@ -64,7 +66,8 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
   const long groups = (total + WAVES - 1) / WAVES;
   if (groups > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)groups;
-  const size_t lds = (size_t)WAVES * EPT * kWave * sizeof(float);
+  size_t lds = (size_t)WAVES * EPT * kWave * sizeof(float);
+  if (const char* extra = getenv("SHW_DEV_EXTRA_LDS")) lds += (size_t)atoi(extra);   // occupancy experiments only
   const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
   const dim3 grid((unsigned)groups), block(WAVES * 64);
   if (A.p_int == 2) {

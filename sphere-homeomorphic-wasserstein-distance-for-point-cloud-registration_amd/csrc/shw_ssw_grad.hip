@@ -1,26 +1,143 @@
-// shw_ssw_grad.hip -- loss + gradient-coefficient kernel for p != 1 (key+index register sort) and
+// shw_ssw_grad.hip -- loss + gradient-coefficient kernel for p != 1 (packed-key register sort) and
 // the coefficient -> point-gradient streaming kernel.  See ssw_common.hpp.
 #include "ssw_common.hpp"
 
 namespace shw {
 
 // ---------------------------------------------------------------------------------------------
-// forward + gradient coefficients.  Same flow as ssw_forward_kernel, but both sorts carry the
-// original point index (wave_sort_kv), the sorted target indices are parked in LDS next to the
-// sorted target coordinates, and after the shift solve every sorted source position e writes
+// forward + gradient coefficients (training).
+//
+// The permutation is needed as well as the sorted values.  Carrying a 64-bit (key, index) item through
+// the network costs 2.6x the VALU work of the key-only sort (v_cmp_u64 + v_cndmask pairs instead of
+// v_min/v_max/v_med3; measured 1.46 ms vs 0.35 ms per launch at config 3), so the sort runs on ONE
+// 32-bit word per atom instead:
+//     packed = (floor(coord * 2^QBITS) << IDX_BITS) | original index ,  IDX_BITS = log2(64*EPT)
+// (QBITS = 21 at N = 2048) with the unsigned-integer form of the same register network.  Packed keys are
+// unique, so the result is ordered by quantised coordinate, ties by original index.  The exact fp32
+// coordinates are then gathered by index from an LDS copy, and atoms whose quantised coordinates
+// collide (distance < 2^-QBITS; ~1 pair per slice at N = 2048) are put into exact order by an
+// odd-even transposition fix-up that runs only when a collision is detected and loops until no
+// exchange happens.  The final order is the stable ascending order of the fp32 coordinates -- the
+// order torch.sort gives the reference (:163-164) -- and deterministic.
+//
+// After the shift solve, sorted source position e writes
 //     coef_s[slice, idx_u(e)]        = +g ,   g = (1/n) d|D|^p/dD ,  D = u_(e) - v_ext(e + k*)
 //     coef_t[slice, idx_v(e + k*)]   = -g
-// i.e. d cost / d coordinate in ORIGINAL point order.  Each wave writes every
-// entry of its 2 x n coefficient rows exactly once (the sort permutations are bijections), so the
-// scratch needs no zero fill and the result is deterministic.
+// i.e. d cost / d coordinate in ORIGINAL point order.  Every entry of the two
+// coefficient rows is written exactly once (the permutations are bijections): no zero fill, no atomics.
 // ---------------------------------------------------------------------------------------------
-template <int EPT, int WAVES, int PMODE>
+template <int EPT>
+struct Packing {
+  static constexpr int IDX_BITS = __builtin_ctz(EPT * kWave);
+  static constexpr int QBITS = 32 - IDX_BITS;
+  static constexpr unsigned IDX_MASK = (1u << IDX_BITS) - 1u;
+  static __device__ __forceinline__ unsigned pack(float coord, int idx, bool live) {
+    // coord in [0, 1]; 2^QBITS * coord is exact in fp32 for QBITS <= 26 and fits 32 bits
+    const float scaled = coord * (float)(1u << (QBITS > 26 ? 26 : QBITS));
+    unsigned q = (unsigned)scaled;
+    if constexpr (QBITS > 26) q <<= (QBITS - 26);
+    const unsigned qmax = (QBITS >= 32) ? 0xffffffffu : ((1u << QBITS) - 1u);
+    q = q < qmax ? q : qmax;
+    return live ? ((q << IDX_BITS) | (unsigned)idx) : 0xffffffffu;
+  }
+};
+
+// (value, index) pair order: ascending value, ties by ascending index
+__device__ __forceinline__ bool pair_after(float va, int ia, float vb, int ib) {
+  return (va > vb) || (va == vb && ia > ib);
+}
+
+// Put a nearly sorted (val, idx) sequence -- sorted position lane*EPT + r -- into exact stable order.
+// One round = exchange of pairs (2j, 2j+1) then (2j+1, 2j+2); rounds repeat until a round is clean.
+template <int EPT>
+__device__ __forceinline__ void exact_order_fixup(float (&val)[EPT], int (&idx)[EPT], int lane) {
+  for (int round = 0; round < EPT * kWave; ++round) {       // bound: odd-even transposition sorts in n rounds
+    bool any = false;
+    auto exch = [&](float& va, int& ia, float& vb, int& ib) {
+      const bool sw = pair_after(va, ia, vb, ib);
+      const float tv = va; const int ti = ia;
+      va = sw ? vb : va; ia = sw ? ib : ia;
+      vb = sw ? tv : vb; ib = sw ? ti : ib;
+      any |= sw;
+    };
+#pragma unroll
+    for (int r = 0; r + 1 < EPT; r += 2) exch(val[r], idx[r], val[r + 1], idx[r + 1]);
+#pragma unroll
+    for (int r = 1; r + 1 < EPT; r += 2) exch(val[r], idx[r], val[r + 1], idx[r + 1]);
+    {  // boundary pair: this lane's last atom against the next lane's first
+      const int up = min(lane + 1, 63) << 2, dn = max(lane - 1, 0) << 2;
+      const float nv = as_f(__builtin_amdgcn_ds_bpermute(up, as_i(val[0])));
+      const int ni = __builtin_amdgcn_ds_bpermute(up, idx[0]);
+      const float pv = as_f(__builtin_amdgcn_ds_bpermute(dn, as_i(val[EPT - 1])));
+      const int pi = __builtin_amdgcn_ds_bpermute(dn, idx[EPT - 1]);
+      const bool sw_up = (lane < 63) && pair_after(val[EPT - 1], idx[EPT - 1], nv, ni);
+      const bool sw_dn = (lane > 0) && pair_after(pv, pi, val[0], idx[0]);
+      if constexpr (EPT == 1) {
+        // a lane's single atom can be wanted by both neighbours: alternate even / odd boundaries
+        const bool even_phase = (round & 1) == 0;
+        const bool do_up = sw_up && (((lane & 1) == 0) == even_phase);
+        const bool do_dn = sw_dn && (((lane & 1) == 1) == even_phase);
+        val[0] = do_up ? nv : (do_dn ? pv : val[0]);
+        idx[0] = do_up ? ni : (do_dn ? pi : idx[0]);
+        any |= sw_up || sw_dn;
+      } else {
+        val[EPT - 1] = sw_up ? nv : val[EPT - 1]; idx[EPT - 1] = sw_up ? ni : idx[EPT - 1];
+        val[0] = sw_dn ? pv : val[0]; idx[0] = sw_dn ? pi : idx[0];
+        any |= sw_up || sw_dn;
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(any) != 0ull)) == 0) break;
+  }
+}
+
+// project one cloud, sort it (packed keys), recover exact sorted coordinates + original indices
+template <int EPT>
+__device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X, int count, int lane,
+                                                     const float (&U)[6], float* orig, float (&val)[EPT],
+                                                     int (&idx)[EPT]) {
+  typedef Packing<EPT> PK;
+  unsigned pk[EPT];
+  float part;
+  {
+    float key[EPT];
+    part = load_coords<EPT>(X, count, lane, U, key);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * kWave + lane;
+      orig[i] = key[r];                                  // exact coordinate by ORIGINAL index (pads: +inf)
+      pk[r] = PK::pack(key[r], i, i < count);
+    }
+  }
+  wave_sort<EPT>(pk, lane);
+  __builtin_amdgcn_wave_barrier();
+  bool collide = false;                                  // equal quantised coordinate on adjacent atoms?
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const bool pad = pk[r] == 0xffffffffu;
+    idx[r] = pad ? (int)PK::IDX_MASK : (int)(pk[r] & PK::IDX_MASK);
+    val[r] = pad ? __builtin_inff() : orig[idx[r]];
+    if (r > 0) collide |= ((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0 && !pad;
+  }
+  {
+    const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)pk[0]);
+    collide |= (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) && (pk[EPT - 1] != 0xffffffffu);
+  }
+  if (__builtin_amdgcn_readfirstlane((int)(__ballot(collide) != 0ull)) != 0) exact_order_fixup<EPT>(val, idx, lane);
+  __builtin_amdgcn_wave_barrier();
+  return part;
+}
+
+template <int EPT, int WAVES, int PMODE, bool FULL>
 __global__ __launch_bounds__(WAVES * 64) void ssw_forward_grad_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ROW = EPT * kWave;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* vbuf = lds + wave * (2 * EPT * kWave);
-  int* vidx = reinterpret_cast<int*>(vbuf + EPT * kWave);
+  // LDS per wave: sorted target coordinates (4 B), coordinates by original index / coefficient staging
+  // (4 B), sorted target original indices (2 B)  =  10 B per atom (20 KB at N = 2048)
+  float* vbuf = lds + wave * (ROW * 5 / 2);
+  float* orig = vbuf + ROW;
+  unsigned short* vidx = reinterpret_cast<unsigned short*>(orig + ROW);
 
   const int vid = xcd_contiguous_id(blockIdx.x, A.num_groups);
   const int s = vid * WAVES + wave;
@@ -33,7 +150,8 @@ __global__ __launch_bounds__(WAVES * 64) void ssw_forward_grad_kernel(SswArgs A)
 #pragma unroll
   for (int i = 0; i < 6; ++i) U[i] = Ul[i];
 
-  item_t item[EPT];
+  float u[EPT];
+  int uidx[EPT];
   float sum_v = 0.f, sum_u = 0.f;
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {
@@ -41,17 +159,13 @@ __global__ __launch_bounds__(WAVES * 64) void ssw_forward_grad_kernel(SswArgs A)
     const int count = which == 0 ? A.m : n;
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    float key[EPT];
-    const float part = load_coords<EPT>(X, count, ln, U, key);
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) item[r] = make_item(key[r], r * kWave + ln);
-    wave_sort_kv<EPT>(item, ln);
+    const float part = sorted_with_indices<EPT>(X, count, ln, U, orig, u, uidx);
     if (which == 0) {
       sum_v = wave_sum(part, lane);
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {
-        vbuf[r * kWave + lane] = item_key(item[r]);
-        vidx[r * kWave + lane] = item_idx(item[r]);
+        vbuf[r * kWave + lane] = u[r];
+        vidx[r * kWave + lane] = (unsigned short)uidx[r];
       }
     } else {
       sum_u = wave_sum(part, lane);
@@ -59,42 +173,60 @@ __global__ __launch_bounds__(WAVES * 64) void ssw_forward_grad_kernel(SswArgs A)
   }
   __builtin_amdgcn_wave_barrier();
 
-  float u[EPT];
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) u[r] = item_key(item[r]);
   float best;
-  const int k = solve_shift<EPT, PMODE>(u, vbuf, lane, n, sum_u, sum_v, A.p, A.p_int, best);
+  const int k = solve_shift<EPT, PMODE, FULL>(u, vbuf, lane, n, sum_u, sum_v, A.p, A.p_int, best);
   const float inv_n = 1.f / (float)n;
   if (lane == 0) {
     A.slice_cost[s] = best * inv_n;
     if (A.slice_shift) A.slice_shift[s] = k;
   }
+  // coefficients: un-permute through the LDS staging row, then store coalesced (a direct scatter to
+  // global memory costs one address per lane per store: ~0.2 ms per launch at config 3)
   float* cs = A.coef_s + (long)s * n;
   float* ct = A.coef_t + (long)s * A.m;
+  float g[EPT];
+  int tslot[EPT];
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int e = lane * EPT + r;
-    if (e < n) {
-      int q = e + k;                                 // in [-n, 2n): one turn at most
-      float off = 0.f;
-      if (q < 0) { q += n; off = -1.f; }
-      else if (q >= n) { q -= n; off = 1.f; }
-      const int slot = lds_slot<EPT>(q);
-      const float d = u[r] - (vbuf[slot] + off);
-      const float g = dpow_abs<PMODE>(d, A.p, A.p_int) * inv_n;
-      cs[item_idx(item[r])] = g;
-      ct[vidx[slot]] = -g;
-    }
+    int q = min(e, n - 1) + k;                       // in [-n, 2n): one turn at most
+    float off = 0.f;
+    if (q < 0) { q += n; off = -1.f; }
+    else if (q >= n) { q -= n; off = 1.f; }
+    tslot[r] = lds_slot<EPT>(q);
+    const float d = u[r] - (vbuf[tslot[r]] + off);
+    g[r] = dpow_abs<PMODE>(d, A.p, A.p_int) * inv_n;
+    if (e < n) orig[uidx[r]] = g[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int i = r * kWave + lane;
+    if (i < n) cs[i] = orig[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    if (e < n) orig[vidx[tslot[r]]] = -g[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int i = r * kWave + lane;
+    if (i < A.m) ct[i] = orig[i];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// coefficient rows -> point gradients.  One thread per (pair, cloud, point) walks the slices:
+// coefficient rows -> point gradients:
 //   grad[b,i,:] = scale * sum_l coef[b,l,i] * (-bb U_l[:,0] + a U_l[:,1]) / (2 pi (a^2 + bb^2)),
 //   (a, bb) = U_l^T x[b,i].
-// Streams the coefficient scratch once, coalesced over i (the HBM-bound kernel of this path);
-// directions are wave-uniform scalar loads.  Four interleaved partial sums per component keep the
-// slice sum's rounding error at the sqrt(L/4) level and the loads in flight.
+// The HBM-bound kernel of the path: it streams the coefficient scratch exactly once.  A workgroup owns
+// 64 consecutive points of one cloud of one pair; its 4 waves split the slices 4 ways (wave w takes
+// slices w, w+4, ...), each lane keeps 8 coalesced loads in flight, and the 4 partial sums are added
+// in wave order through LDS -- fixed order, no atomics, bitwise reproducible.  Directions are
+// wave-uniform scalar loads.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* __restrict__ xs,
                                                                   const float* __restrict__ xt,
@@ -104,47 +236,47 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
                                                                   int slices, long u_pair_stride, float scale,
                                                                   float* __restrict__ grad_xs,
                                                                   float* __restrict__ grad_xt, int chunks_s) {
+  __shared__ float part[3][4][64];
   const int b = blockIdx.y;
   const bool is_t = (int)blockIdx.x >= chunks_s;
   const int chunk = is_t ? blockIdx.x - chunks_s : blockIdx.x;
   const int cnt = is_t ? m : n;
-  const int i = chunk * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = chunk * 64 + lane;
   const float* X = (is_t ? xt : xs) + (long)b * cnt * 3;
   const float* C = (is_t ? coef_t : coef_s) + (long)b * slices * cnt;
   float* G = (is_t ? grad_xt : grad_xs) + (long)b * cnt * 3;
   const float* Ub = dirs + (long)b * u_pair_stride;
   const int ic = min(i, cnt - 1);
   const float px = X[3 * ic], py = X[3 * ic + 1], pz = X[3 * ic + 2];
-  float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
   const float inv_two_pi = 0.159154936671257019f;
-  int l = 0;
-  for (; l + 4 <= slices; l += 4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float* U = Ub + (long)(l + j) * 6;
-      const float c = C[(long)(l + j) * cnt + ic];
-      const float a = fmaf(pz, U[4], fmaf(py, U[2], px * U[0]));
-      const float bb = fmaf(pz, U[5], fmaf(py, U[3], px * U[1]));
-      const float w = c * inv_two_pi / fmaf(a, a, bb * bb);
-      gx[j] = fmaf(w, fmaf(a, U[1], -bb * U[0]), gx[j]);
-      gy[j] = fmaf(w, fmaf(a, U[3], -bb * U[2]), gy[j]);
-      gz[j] = fmaf(w, fmaf(a, U[5], -bb * U[4]), gz[j]);
-    }
-  }
-  for (; l < slices; ++l) {
-    const float* U = Ub + (long)l * 6;
-    const float c = C[(long)l * cnt + ic];
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  auto add = [&](float c, const float* U) {
     const float a = fmaf(pz, U[4], fmaf(py, U[2], px * U[0]));
     const float bb = fmaf(pz, U[5], fmaf(py, U[3], px * U[1]));
     const float w = c * inv_two_pi / fmaf(a, a, bb * bb);
-    gx[0] = fmaf(w, fmaf(a, U[1], -bb * U[0]), gx[0]);
-    gy[0] = fmaf(w, fmaf(a, U[3], -bb * U[2]), gy[0]);
-    gz[0] = fmaf(w, fmaf(a, U[5], -bb * U[4]), gz[0]);
+    gx = fmaf(w, fmaf(a, U[1], -bb * U[0]), gx);
+    gy = fmaf(w, fmaf(a, U[3], -bb * U[2]), gy);
+    gz = fmaf(w, fmaf(a, U[5], -bb * U[4]), gz);
+  };
+  int l = wave;
+  for (; l + 28 < slices; l += 32) {                 // 8 slices of this wave per trip, loads first
+    float c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = C[(long)(l + 4 * j) * cnt + ic];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) add(c[j], Ub + (long)(l + 4 * j) * 6);
   }
-  if (i < cnt) {
-    G[3 * i] = ((gx[0] + gx[1]) + (gx[2] + gx[3])) * scale;
-    G[3 * i + 1] = ((gy[0] + gy[1]) + (gy[2] + gy[3])) * scale;
-    G[3 * i + 2] = ((gz[0] + gz[1]) + (gz[2] + gz[3])) * scale;
+  for (; l < slices; l += 4) add(C[(long)l * cnt + ic], Ub + (long)l * 6);
+  part[0][wave][lane] = gx;
+  part[1][wave][lane] = gy;
+  part[2][wave][lane] = gz;
+  __syncthreads();
+  if (wave == 0 && i < cnt) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      G[3 * i + d] = (((part[d][0][lane] + part[d][1][lane]) + part[d][2][lane]) + part[d][3][lane]) * scale;
   }
 }
 
@@ -154,11 +286,15 @@ static int launch_forward_grad(SswArgs& A, hipStream_t stream) {
   const long groups = (total + WAVES - 1) / WAVES;
   if (groups > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)groups;
-  const size_t lds = (size_t)WAVES * 2 * EPT * kWave * sizeof(float);
+  const size_t lds = (size_t)WAVES * (EPT * kWave * 10);
+  const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
+  const dim3 grid((unsigned)groups), block(WAVES * 64);
   if (A.p_int == 2) {
-    hipLaunchKernelGGL((ssw_forward_grad_kernel<EPT, WAVES, 2>), dim3((unsigned)groups), dim3(WAVES * 64), lds, stream, A);
+    if (full) hipLaunchKernelGGL((ssw_forward_grad_kernel<EPT, WAVES, 2, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_grad_kernel<EPT, WAVES, 2, false>), grid, block, lds, stream, A);
   } else {
-    hipLaunchKernelGGL((ssw_forward_grad_kernel<EPT, WAVES, 0>), dim3((unsigned)groups), dim3(WAVES * 64), lds, stream, A);
+    if (full) hipLaunchKernelGGL((ssw_forward_grad_kernel<EPT, WAVES, 0, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_grad_kernel<EPT, WAVES, 0, false>), grid, block, lds, stream, A);
   }
   return (int)hipGetLastError();
 }
@@ -166,14 +302,14 @@ static int launch_forward_grad(SswArgs& A, hipStream_t stream) {
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream) {
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT
-    case SHW_DEV_ONLY_EPT: return launch_forward_grad<SHW_DEV_ONLY_EPT, (SHW_DEV_ONLY_EPT <= 32 ? 2 : 1)>(A, stream);
+    case SHW_DEV_ONLY_EPT: return launch_forward_grad<SHW_DEV_ONLY_EPT, 1>(A, stream);
 #else
     case 1: return launch_forward_grad<1, 4>(A, stream);
     case 2: return launch_forward_grad<2, 4>(A, stream);
     case 4: return launch_forward_grad<4, 4>(A, stream);
     case 8: return launch_forward_grad<8, 4>(A, stream);
     case 16: return launch_forward_grad<16, 4>(A, stream);
-    case 32: return launch_forward_grad<32, 2>(A, stream);
+    case 32: return launch_forward_grad<32, 1>(A, stream);
     case 64: return launch_forward_grad<64, 1>(A, stream);
     case 128: return launch_forward_grad<128, 1>(A, stream);
 #endif
@@ -185,7 +321,7 @@ int dispatch_forward_grad(SswArgs& A, hipStream_t stream) {
 int launch_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
                            const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride,
                            float scale, float* grad_xs, float* grad_xt, hipStream_t stream) {
-  const int chunks_s = (n + 255) / 256, chunks_t = (m + 255) / 256;
+  const int chunks_s = (n + 63) / 64, chunks_t = (m + 63) / 64;
   hipLaunchKernelGGL(ssw_backward_points_kernel, dim3(chunks_s + chunks_t, pairs), dim3(256), 0, stream, xs, xt, dirs,
                      coef_s, coef_t, n, m, slices, u_pair_stride, scale, grad_xs, grad_xt, chunks_s);
   return (int)hipGetLastError();

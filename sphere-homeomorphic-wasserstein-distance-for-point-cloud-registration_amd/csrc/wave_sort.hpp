@@ -59,79 +59,109 @@ __device__ __forceinline__ float lane_xor(float x, int lane) {
   }
 }
 
-__device__ __forceinline__ void cmp_swap(float& lo, float& hi) {
-  const float a = lo, b = hi;
-  lo = __builtin_fminf(a, b);
-  hi = __builtin_fmaxf(a, b);
+// ---- key policies: what a compare-exchange is for a 32-bit key type ------------------------------
+struct F32Keys {                      // float keys (circle coordinates, +inf padding)
+  typedef float type;
+  static __device__ __forceinline__ float lo(float a, float b) { return __builtin_fminf(a, b); }
+  static __device__ __forceinline__ float hi(float a, float b) { return __builtin_fmaxf(a, b); }
+  // lower lane keeps min(x, p), upper lane keeps max(x, p): one v_med3_f32 against -inf / +inf
+  static __device__ __forceinline__ float bound(bool upper) { return upper ? __builtin_inff() : -__builtin_inff(); }
+  static __device__ __forceinline__ float pick(float x, float p, float bnd) { return __builtin_amdgcn_fmed3f(x, p, bnd); }
+};
+struct U32Keys {                      // unsigned keys (packed quantised coordinate | original index)
+  typedef unsigned type;
+  static __device__ __forceinline__ unsigned lo(unsigned a, unsigned b) { return a < b ? a : b; }
+  static __device__ __forceinline__ unsigned hi(unsigned a, unsigned b) { return a < b ? b : a; }
+  static __device__ __forceinline__ unsigned bound(bool upper) { return upper ? 0xffffffffu : 0u; }
+  static __device__ __forceinline__ unsigned pick(unsigned x, unsigned p, unsigned bnd) {
+    unsigned r;                        // v_med3_u32 has no clang builtin; a plain VALU op needs no wait states
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(p), "v"(bnd));
+    return r;
+  }
+};
+
+template <int MASK>
+__device__ __forceinline__ unsigned lane_xor(unsigned x, int lane) {
+  return (unsigned)as_i(lane_xor<MASK>(as_f((int)x), lane));
+}
+
+template <class P>
+__device__ __forceinline__ void cmp_swap(typename P::type& lo, typename P::type& hi) {
+  const typename P::type a = lo, b = hi;
+  lo = P::lo(a, b);
+  hi = P::hi(a, b);
 }
 
 // in-lane half-cleaner stages with strides J, J/2, ..., 1 (ascending, compile-time register pairs)
-template <int EPT, int J>
-__device__ __forceinline__ void lane_stages(float (&x)[EPT]) {
+template <class P, int EPT, int J>
+__device__ __forceinline__ void lane_stages(typename P::type (&x)[EPT]) {
   if constexpr (J >= 1) {
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
-      if ((r & J) == 0) cmp_swap(x[r], x[r | J]);
+      if ((r & J) == 0) cmp_swap<P>(x[r], x[r | J]);
     }
-    lane_stages<EPT, J / 2>(x);
+    lane_stages<P, EPT, J / 2>(x);
   }
 }
 
 // in-lane merges of size K = 2, 4, ..., EPT
-template <int EPT, int K>
-__device__ __forceinline__ void lane_merges(float (&x)[EPT]) {
+template <class P, int EPT, int K>
+__device__ __forceinline__ void lane_merges(typename P::type (&x)[EPT]) {
   if constexpr (K <= EPT) {
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
       const int q = r ^ (K - 1);
-      if (q > r) cmp_swap(x[r], x[q]);
+      if (q > r) cmp_swap<P>(x[r], x[q]);
     }
-    lane_stages<EPT, K / 4>(x);
-    lane_merges<EPT, K * 2>(x);
+    lane_stages<P, EPT, K / 4>(x);
+    lane_merges<P, EPT, K * 2>(x);
   }
 }
 
 // cross-lane xor stages with lane masks M, M/2, ..., 1
-template <int EPT, int M>
-__device__ __forceinline__ void xlane_stages(float (&x)[EPT], int lane) {
+template <class P, int EPT, int M>
+__device__ __forceinline__ void xlane_stages(typename P::type (&x)[EPT], int lane) {
   if constexpr (M >= 1) {
-    const float bound = (lane & M) ? __builtin_inff() : -__builtin_inff();
+    const typename P::type bnd = P::bound((lane & M) != 0);
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      x[r] = __builtin_amdgcn_fmed3f(x[r], lane_xor<M>(x[r], lane), bound);
-    }
-    xlane_stages<EPT, M / 2>(x, lane);
+    for (int r = 0; r < EPT; ++r) x[r] = P::pick(x[r], lane_xor<M>(x[r], lane), bnd);
+    xlane_stages<P, EPT, M / 2>(x, lane);
   }
 }
 
 // merges spanning 2^C lanes, C = 1 .. 6
-template <int EPT, int C>
-__device__ __forceinline__ void xlane_merges(float (&x)[EPT], int lane) {
+template <class P, int EPT, int C>
+__device__ __forceinline__ void xlane_merges(typename P::type (&x)[EPT], int lane) {
   if constexpr (C <= 6) {
     constexpr int MASK = (1 << C) - 1;
-    const float bound = (lane & (1 << (C - 1))) ? __builtin_inff() : -__builtin_inff();
+    const typename P::type bnd = P::bound((lane & (1 << (C - 1))) != 0);
     if constexpr (EPT == 1) {
-      x[0] = __builtin_amdgcn_fmed3f(x[0], lane_xor<MASK>(x[0], lane), bound);
+      x[0] = P::pick(x[0], lane_xor<MASK>(x[0], lane), bnd);
     } else {
 #pragma unroll
       for (int r = 0; r < EPT / 2; ++r) {          // mirror pairs (r, EPT-1-r): two temporaries live
-        const float pa = lane_xor<MASK>(x[EPT - 1 - r], lane);
-        const float pb = lane_xor<MASK>(x[r], lane);
-        x[r] = __builtin_amdgcn_fmed3f(x[r], pa, bound);
-        x[EPT - 1 - r] = __builtin_amdgcn_fmed3f(x[EPT - 1 - r], pb, bound);
+        const typename P::type pa = lane_xor<MASK>(x[EPT - 1 - r], lane);
+        const typename P::type pb = lane_xor<MASK>(x[r], lane);
+        x[r] = P::pick(x[r], pa, bnd);
+        x[EPT - 1 - r] = P::pick(x[EPT - 1 - r], pb, bnd);
       }
     }
-    xlane_stages<EPT, (1 << C) / 4>(x, lane);
-    lane_stages<EPT, EPT / 2>(x);
-    xlane_merges<EPT, C + 1>(x, lane);
+    xlane_stages<P, EPT, (1 << C) / 4>(x, lane);
+    lane_stages<P, EPT, EPT / 2>(x);
+    xlane_merges<P, EPT, C + 1>(x, lane);
   }
 }
 
 // ascending sort of the 64*EPT keys of a wave; sorted position of x[r] in lane `lane` is lane*EPT + r.
 template <int EPT>
 __device__ __forceinline__ void wave_sort(float (&x)[EPT], int lane) {
-  lane_merges<EPT, 2>(x);
-  xlane_merges<EPT, 1>(x, lane);
+  lane_merges<F32Keys, EPT, 2>(x);
+  xlane_merges<F32Keys, EPT, 1>(x, lane);
+}
+template <int EPT>
+__device__ __forceinline__ void wave_sort(unsigned (&x)[EPT], int lane) {
+  lane_merges<U32Keys, EPT, 2>(x);
+  xlane_merges<U32Keys, EPT, 1>(x, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

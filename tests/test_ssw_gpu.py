@@ -237,6 +237,37 @@ def test_sizes_against_cpu_oracle(shw, n, p):
         assert np.allclose(cost[0].cpu().numpy(), mirror, rtol=5e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("n", [3000, 4096, 5000, 8192])
+def test_large_sizes_against_cpu_oracle(shw, n):
+    """Size classes above the headline one (64 and 128 keys per lane), loss and gradients."""
+    from oracle import exact_shift
+    g = torch.Generator().manual_seed(4000 + n)
+    L = 3
+    x, y, U = unit_cloud(g, n), unit_cloud(g, n), directions(g, L)
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, _ = shw.ssw_pair_losses(xs.unsqueeze(0), ys.unsqueeze(0), U.cuda(), p=2, return_slices=True)
+    pair.sum().backward()
+    cu = exact_shift.circle_coords(x.numpy(), U.numpy())
+    cv = exact_shift.circle_coords(y.numpy(), U.numpy())
+    ref64, _ = exact_shift.circular_ot_equal(cu, cv, p=2)
+    assert np.allclose(cost[0].detach().cpu().numpy(), ref64, rtol=3e-5, atol=1e-10)
+    nograd = shw.ssw_pair_losses(x.cuda().unsqueeze(0), y.cuda().unsqueeze(0), U.cuda(), p=2)
+    assert abs(nograd.item() - pair.item()) < 1e-6 * pair.item()      # loss-only and training kernels agree
+    gx, gy = exact_shift.ssw_pair_grad(x.numpy(), y.numpy(), U.numpy(), p=2)
+    grad_close(xs.grad.cpu().numpy(), gx)
+    grad_close(ys.grad.cpu().numpy(), gy)
+    ref1 = np.array([exact_shift.w1_level_median(cu[l], cv[l]) for l in range(L)])
+    _, cost1, _ = shw.ssw_pair_losses(x.cuda().unsqueeze(0), y.cuda().unsqueeze(0), U.cuda(), p=1, return_slices=True)
+    assert np.allclose(cost1[0].cpu().numpy(), ref1, rtol=5e-5, atol=1e-10)
+
+
+def test_sizes_beyond_the_limit_are_rejected(shw):
+    x = torch.zeros(1, 8193, 3, device="cuda")
+    U = torch.zeros(1, 2, 3, 2, device="cuda")
+    with pytest.raises(RuntimeError):
+        shw.ssw_pair_losses(x, x, U, p=2)
+
+
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (63, 65), (64, 64), (100, 100), (200, 256), (1000, 777),
                                  (1024, 1024), (2048, 2048)])
 def test_sizes_p1_against_cpu_oracle(shw, n, m):
