@@ -46,8 +46,8 @@ int shw_max_points(void);
  *   slice_cost  (pairs*slices) fp32 out : circular OT cost W_p^p of every (pair, slice).
  *   slice_shift (pairs*slices) int32 out, may be NULL : optimal cyclic shift k* of the sorted
  *                target against the sorted source (p != 1), or the median level (p == 1).
- * Supported in this ABI version: uniform weights; n == m for p != 1; any n, m for p == 1;
- * 1 <= n, m <= SHW_MAX_POINTS.
+ * This entry point: uniform weights; n == m for p != 1; any n, m for p == 1; 1 <= n, m <= SHW_MAX_POINTS.
+ * (n != m or weights with p != 1: shw_ssw_forward_general.)
  */
 int shw_ssw_forward(const float* xs, const float* xt, const float* dirs,
                     int pairs, int n, int m, int slices, long u_pair_stride, float p,
@@ -89,6 +89,23 @@ int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
                             const float* coef_s, const float* coef_t,
                             int pairs, int n, int m, int slices, long u_pair_stride, float scale,
                             float* grad_xs, float* grad_xt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spherical sliced-Wasserstein, general circular OT for p != 1: n != m and / or non-uniform weights.
+ * Replaces: binary_search_circle with u_weights / v_weights and unequal sample counts
+ * (max_spherical_sliced_w.py:117-207, dCost :25-65, Cost :68-113), reached from sliced_cost (:284) when the
+ * trainers use different source / target densities (train_W_COS.py:292-293,334-336) or the caller passes
+ * weights (:289).  Follows the reference's bisection over the cut theta and its tangent exit.
+ *   wu (n) or (pairs, n), wv (m) or (pairs, m): non-negative weights summing to 1, NULL = uniform;
+ *   w*_pair_stride = 0 when one weight vector is shared by all pairs (the reference's usage), else n / m.
+ *   slice_theta (pairs*slices) fp32 out, may be NULL : the cut the solve ended on.
+ *   coef_s / coef_t as in shw_ssw_forward_grad, both NULL for a loss-only evaluation.
+ * 1 <= n, m <= 4096 on this path.
+ */
+int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
+                            const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
+                            int pairs, int n, int m, int slices, long u_pair_stride, float p,
+                            float* slice_cost, float* slice_theta, float* coef_s, float* coef_t, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Chamfer distance (comparison baseline).

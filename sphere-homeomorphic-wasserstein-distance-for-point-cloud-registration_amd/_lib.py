@@ -26,6 +26,9 @@ _SIGNATURES = {
     "shw_ssw_forward_grad": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_long, ctypes.c_float, _c_f32p, ctypes.c_void_p,
                                             _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "shw_ssw_forward_general": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_long, ctypes.c_long,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                               ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_ssw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                                ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p]),

@@ -132,6 +132,25 @@ int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs, in
   return shw::dispatch_forward_grad(A, (hipStream_t)stream);
 }
 
+int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs, const float* wu, const float* wv,
+                            long wu_pair_stride, long wv_pair_stride, int pairs, int n, int m, int slices,
+                            long u_pair_stride, float p, float* slice_cost, float* slice_theta, float* coef_s,
+                            float* coef_t, void* stream) {
+  if (!xs || !xt || !dirs || !slice_cost) return (int)hipErrorInvalidValue;
+  if ((coef_s == nullptr) != (coef_t == nullptr)) return (int)hipErrorInvalidValue;
+  if (pairs < 0 || slices < 0 || n < 1 || m < 1 || n > 4096 || m > 4096) return (int)hipErrorInvalidValue;
+  if (!(p > 1.f)) return (int)hipErrorInvalidValue;                // p == 1 is the level-median kernel
+  if (u_pair_stride != 0 && u_pair_stride < (long)slices * 6) return (int)hipErrorInvalidValue;
+  if ((wu_pair_stride != 0 && wu_pair_stride < n) || (wv_pair_stride != 0 && wv_pair_stride < m)) return (int)hipErrorInvalidValue;
+  if (pairs == 0 || slices == 0) return 0;
+  shw::SswArgs A{};
+  A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = nullptr;
+  A.coef_s = coef_s; A.coef_t = coef_t;
+  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride;
+  A.p = p; A.p_int = shw::small_integer_power(p);
+  return shw::dispatch_general(A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, (hipStream_t)stream);
+}
+
 int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
                             const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride, float scale,
                             float* grad_xs, float* grad_xt, void* stream) {

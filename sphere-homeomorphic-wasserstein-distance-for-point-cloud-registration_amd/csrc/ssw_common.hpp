@@ -298,6 +298,110 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
 
 
 // ---------------------------------------------------------------------------------------------
+// sort WITH the permutation (training and weighted kernels): packed 32-bit keys, see shw_ssw_grad.hip
+// ---------------------------------------------------------------------------------------------
+template <int EPT>
+struct Packing {
+  static constexpr int IDX_BITS = __builtin_ctz(EPT * kWave);
+  static constexpr int QBITS = 32 - IDX_BITS;
+  static constexpr unsigned IDX_MASK = (1u << IDX_BITS) - 1u;
+  static __device__ __forceinline__ unsigned pack(float coord, int idx, bool live) {
+    // coord in [0, 1]; 2^QBITS * coord is exact in fp32 for QBITS <= 26 and fits 32 bits
+    const float scaled = coord * (float)(1u << (QBITS > 26 ? 26 : QBITS));
+    unsigned q = (unsigned)scaled;
+    if constexpr (QBITS > 26) q <<= (QBITS - 26);
+    const unsigned qmax = (QBITS >= 32) ? 0xffffffffu : ((1u << QBITS) - 1u);
+    q = q < qmax ? q : qmax;
+    return live ? ((q << IDX_BITS) | (unsigned)idx) : 0xffffffffu;
+  }
+};
+
+// (value, index) pair order: ascending value, ties by ascending index
+__device__ __forceinline__ bool pair_after(float va, int ia, float vb, int ib) {
+  return (va > vb) || (va == vb && ia > ib);
+}
+
+// Put a nearly sorted (val, idx) sequence -- sorted position lane*EPT + r -- into exact stable order.
+// One round = exchange of pairs (2j, 2j+1) then (2j+1, 2j+2); rounds repeat until a round is clean.
+template <int EPT>
+__device__ __forceinline__ void exact_order_fixup(float (&val)[EPT], int (&idx)[EPT], int lane) {
+  for (int round = 0; round < EPT * kWave; ++round) {       // bound: odd-even transposition sorts in n rounds
+    bool any = false;
+    auto exch = [&](float& va, int& ia, float& vb, int& ib) {
+      const bool sw = pair_after(va, ia, vb, ib);
+      const float tv = va; const int ti = ia;
+      va = sw ? vb : va; ia = sw ? ib : ia;
+      vb = sw ? tv : vb; ib = sw ? ti : ib;
+      any |= sw;
+    };
+#pragma unroll
+    for (int r = 0; r + 1 < EPT; r += 2) exch(val[r], idx[r], val[r + 1], idx[r + 1]);
+#pragma unroll
+    for (int r = 1; r + 1 < EPT; r += 2) exch(val[r], idx[r], val[r + 1], idx[r + 1]);
+    {  // boundary pair: this lane's last atom against the next lane's first
+      const int up = min(lane + 1, 63) << 2, dn = max(lane - 1, 0) << 2;
+      const float nv = as_f(__builtin_amdgcn_ds_bpermute(up, as_i(val[0])));
+      const int ni = __builtin_amdgcn_ds_bpermute(up, idx[0]);
+      const float pv = as_f(__builtin_amdgcn_ds_bpermute(dn, as_i(val[EPT - 1])));
+      const int pi = __builtin_amdgcn_ds_bpermute(dn, idx[EPT - 1]);
+      const bool sw_up = (lane < 63) && pair_after(val[EPT - 1], idx[EPT - 1], nv, ni);
+      const bool sw_dn = (lane > 0) && pair_after(pv, pi, val[0], idx[0]);
+      if constexpr (EPT == 1) {
+        // a lane's single atom can be wanted by both neighbours: alternate even / odd boundaries
+        const bool even_phase = (round & 1) == 0;
+        const bool do_up = sw_up && (((lane & 1) == 0) == even_phase);
+        const bool do_dn = sw_dn && (((lane & 1) == 1) == even_phase);
+        val[0] = do_up ? nv : (do_dn ? pv : val[0]);
+        idx[0] = do_up ? ni : (do_dn ? pi : idx[0]);
+        any |= sw_up || sw_dn;
+      } else {
+        val[EPT - 1] = sw_up ? nv : val[EPT - 1]; idx[EPT - 1] = sw_up ? ni : idx[EPT - 1];
+        val[0] = sw_dn ? pv : val[0]; idx[0] = sw_dn ? pi : idx[0];
+        any |= sw_up || sw_dn;
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(any) != 0ull)) == 0) break;
+  }
+}
+
+// project one cloud, sort it (packed keys), recover exact sorted coordinates + original indices
+template <int EPT>
+__device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X, int count, int lane,
+                                                     const float (&U)[6], float* orig, float (&val)[EPT],
+                                                     int (&idx)[EPT]) {
+  typedef Packing<EPT> PK;
+  unsigned pk[EPT];
+  float part;
+  {
+    float key[EPT];
+    part = load_coords<EPT>(X, count, lane, U, key);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * kWave + lane;
+      orig[i] = key[r];                                  // exact coordinate by ORIGINAL index (pads: +inf)
+      pk[r] = PK::pack(key[r], i, i < count);
+    }
+  }
+  wave_sort<EPT>(pk, lane);
+  __builtin_amdgcn_wave_barrier();
+  bool collide = false;                                  // equal quantised coordinate on adjacent atoms?
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const bool pad = pk[r] == 0xffffffffu;
+    idx[r] = pad ? (int)PK::IDX_MASK : (int)(pk[r] & PK::IDX_MASK);
+    val[r] = pad ? __builtin_inff() : orig[idx[r]];
+    if (r > 0) collide |= ((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0 && !pad;
+  }
+  {
+    const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)pk[0]);
+    collide |= (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) && (pk[EPT - 1] != 0xffffffffu);
+  }
+  if (__builtin_amdgcn_readfirstlane((int)(__ballot(collide) != 0ull)) != 0) exact_order_fixup<EPT>(val, idx, lane);
+  __builtin_amdgcn_wave_barrier();
+  return part;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side helpers shared by the per-kernel translation units
 // ---------------------------------------------------------------------------------------------
 inline int small_integer_power(float p) {
@@ -322,6 +426,8 @@ inline int ept_for(int n, int m) {
 int dispatch_forward(SswArgs& A, hipStream_t stream);        // shw_ssw_fwd.hip   p != 1, loss only
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream);   // shw_ssw_grad.hip  p != 1, loss + coefficients
 int dispatch_level_median(SswArgs& A, hipStream_t stream);   // shw_ssw_p1.hip    p == 1 (coef_s != NULL: + coefficients)
+int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
+                     float* slice_theta, hipStream_t stream);   // shw_ssw_general.hip  p != 1, n != m / weights
 int launch_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
                            const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride,
                            float scale, float* grad_xs, float* grad_xt, hipStream_t stream);

@@ -46,7 +46,7 @@ class _PairLosses(torch.autograd.Function):
     """(B,n,3), (B,m,3), dirs -> (B,) per-pair mean over slices of the circular OT cost W_p^p."""
 
     @staticmethod
-    def forward(ctx, Xs, Xt, Us, p, shared_dirs):
+    def forward(ctx, Xs, Xt, Us, p, shared_dirs, wu, wv):
         lib = _lib.load()
         B, n, _ = Xs.shape
         m = Xt.shape[1]
@@ -59,8 +59,32 @@ class _PairLosses(torch.autograd.Function):
         pair_loss = torch.empty(B, dtype=torch.float32, device=dev)
         need_grad = Xs.requires_grad or Xt.requires_grad
         stream = _stream_ptr(dev)
+        general = float(p) != 1.0 and (n != m or wu is not None or wv is not None)
         with torch.cuda.device(dev):
-            if need_grad:
+            if general:
+                # n != m and / or weights: the reference's bisection over the cut, followed step for step
+                coef_s = coef_t = None
+                if need_grad:
+                    coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev)
+                    coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev)
+                theta = torch.empty(B * L, dtype=torch.float32, device=dev)
+
+                def wargs(w, cnt):
+                    if w is None:
+                        return None, 0
+                    return w.data_ptr(), (0 if w.dim() == 1 else cnt)
+                wu_p, wu_s = wargs(wu, n)
+                wv_p, wv_s = wargs(wv, m)
+                _lib.check(lib.shw_ssw_forward_general(
+                    Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), wu_p, wv_p, wu_s, wv_s, B, n, m, L, stride,
+                    float(p), slice_cost.data_ptr(), theta.data_ptr(),
+                    coef_s.data_ptr() if need_grad else None, coef_t.data_ptr() if need_grad else None, stream),
+                    "shw_ssw_forward_general")
+                slice_shift.zero_()
+                if need_grad:
+                    ctx.save_for_backward(Xs_c, Xt_c, Us_c, coef_s, coef_t)
+                    ctx.dims = (B, n, m, L, stride)
+            elif need_grad:
                 coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev)
                 coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev)
                 _lib.check(lib.shw_ssw_forward_grad(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), B, n, m, L,
@@ -93,11 +117,22 @@ class _PairLosses(torch.autograd.Function):
                                                    1.0 / L, gxs.data_ptr(), gxt.data_ptr(), _stream_ptr(dev)),
                        "shw_ssw_backward_points")
         w = g_pair.to(torch.float32).view(B, 1, 1)
-        return gxs * w, gxt * w, None, None, None
+        return gxs * w, gxt * w, None, None, None, None, None
 
 
-def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False):
-    """Core op: batched clouds (B,n,3), (B,m,3); directions (B,L,3,2) or shared (L,3,2).
+def _check_weights(name, w, count, B, dev):
+    if w is None:
+        return None
+    if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32:
+        raise TypeError(f"{name} must be a float32 device tensor")
+    if tuple(w.shape) not in ((count,), (B, count)):
+        raise ValueError(f"{name} must have shape ({count},) or ({B}, {count}), got {tuple(w.shape)}")
+    return w.detach().contiguous()
+
+
+def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weights=None):
+    """Core op: batched clouds (B,n,3), (B,m,3); directions (B,L,3,2) or shared (L,3,2); optional weights
+    (n,) / (B,n) and (m,) / (B,m) (p != 1 only).
     Returns (B,) per-pair losses = mean over slices of W_p^p on the slice circle
     [optionally also the (B,L) per-slice costs and optimal shifts]."""
     _check_cloud("Xs", Xs)
@@ -110,7 +145,12 @@ def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False):
         raise ValueError("per-pair directions must be (B,L,3,2)")
     if not (float(p) >= 1.0):
         raise ValueError("p must be >= 1")
-    pair, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared)
+    wu = _check_weights("u_weights", u_weights, Xs.shape[1], Xs.shape[0], Xs.device)
+    wv = _check_weights("v_weights", v_weights, Xt.shape[1], Xs.shape[0], Xs.device)
+    if (wu is not None or wv is not None) and float(p) == 1.0:
+        raise NotImplementedError("weights with p == 1 (the level-median kernel assumes uniform weights) are not "
+                                  "implemented in the HIP path; refusing to fall back to a CPU path")
+    pair, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared, wu, wv)
     if return_slices:
         return pair, cost, shift
     return pair
@@ -123,23 +163,15 @@ def _check_cloud_dirs(Us):
         raise ValueError(f"Us must be (L,3,2) or (B,L,3,2), got {tuple(Us.shape)}")
 
 
-def _reject_weights(u_weights, v_weights):
-    if u_weights is not None or v_weights is not None:
-        raise NotImplementedError(
-            "non-uniform u_weights / v_weights are not implemented in the HIP path yet "
-            "(SURVEY.md 8f rank 1); refusing to fall back to a CPU path")
-
-
 def sliced_cost(Xs, Xt, Us, p=2, u_weights=None, v_weights=None):
     """Reference `sliced_cost`.  Per pair -- Xs (n,3), Xt (m,3), Us (L,3,2) -> 0-dim tensor, the mean
     over slices (:286).  Batched -- Xs (B,n,3), Xt (B,m,3), Us (B,L,3,2) -> shape-[1] tensor, the SUM
     over pairs of the per-pair means (_fast.py:291-293).  Batched p == 1, which raises in the
     reference, is evaluated pair-wise here (documented extension)."""
-    _reject_weights(u_weights, v_weights)
     if Xs.dim() == 2:
-        pair = ssw_pair_losses(Xs.unsqueeze(0), Xt.unsqueeze(0), Us, p)
+        pair = ssw_pair_losses(Xs.unsqueeze(0), Xt.unsqueeze(0), Us, p, u_weights=u_weights, v_weights=v_weights)
         return pair[0]
-    pair = ssw_pair_losses(Xs, Xt, Us, p)
+    pair = ssw_pair_losses(Xs, Xt, Us, p, u_weights=u_weights, v_weights=v_weights)
     return pair.sum().reshape(1)
 
 

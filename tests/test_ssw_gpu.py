@@ -182,8 +182,87 @@ def test_g4_unequal_sizes_p1(shw, golden):
     assert np.allclose(cost[0].cpu().numpy(), g["n256_m200_per_slice_p1"], rtol=2e-5, atol=1e-10)
     grad_close(x.grad.cpu().numpy(), g["n256_m200_gx_p1"])
     grad_close(y.grad.cpu().numpy(), g["n256_m200_gy_p1"])
-    with pytest.raises(RuntimeError):
-        shw.sliced_cost(x.detach(), y.detach(), U, p=2)
+
+
+# ------------------------------------------------------------------------------ general solver: n != m, weights
+def test_g4_unequal_sizes_p2_general_solver(shw, golden):
+    g = golden("g4_edges.npz")
+    x, y, U = dev(g["x"]).requires_grad_(True), dev(g["y200"]).requires_grad_(True), dev(g["U"])
+    pair, cost, _ = shw.ssw_pair_losses(x.unsqueeze(0), y.unsqueeze(0), U, p=2, return_slices=True)
+    pair.sum().backward()
+    assert rel(pair[0].item(), g["n256_m200_loss_p2"]) < 1e-5
+    assert np.allclose(cost[0].cpu().numpy(), g["n256_m200_per_slice_p2"], rtol=3e-5, atol=1e-10)
+    grad_close(x.grad.cpu().numpy(), g["n256_m200_gx_p2"])
+    grad_close(y.grad.cpu().numpy(), g["n256_m200_gy_p2"])
+
+
+def test_g4_weighted_p2_general_solver(shw, golden):
+    g = golden("g4_edges.npz")
+    x, y, U = dev(g["x128"]), dev(g["y128"]), dev(g["U"])
+    val = shw.sliced_cost(x, y, U, p=2, u_weights=dev(g["wu"]), v_weights=dev(g["wv"]))
+    assert val.dim() == 0
+    assert rel(val.item(), g["weighted_loss_p2"]) < 1e-5
+    with pytest.raises(NotImplementedError):
+        shw.sliced_cost(x, y, U, p=1, u_weights=dev(g["wu"]), v_weights=dev(g["wv"]))
+
+
+@pytest.mark.parametrize("p", [2, 3])
+def test_g3_unequal_rows_through_planar_embedding(shw, golden, p):
+    g = golden("g3_circle.npz")
+    u, v = g["u_128x100"].astype(np.float64), g["v_128x100"].astype(np.float64)
+
+    def embed(c):
+        ang = 2 * np.pi * c
+        return np.stack([np.cos(ang), np.sin(ang), np.zeros_like(ang)], -1).astype(np.float32)
+
+    U = np.zeros((1, 3, 2), dtype=np.float32)
+    U[0, 0, 0] = U[0, 1, 1] = 1.0
+    _, cost, _ = shw.ssw_pair_losses(dev(embed(u)), dev(embed(v)), dev(U), p=p, return_slices=True)
+    assert rel(cost[:, 0].cpu().numpy(), g[f"bsc_p{p}_128x100_f64"]) < 1e-4
+
+
+@pytest.mark.parametrize("n,m,weighted", [(64, 64, True), (100, 37, False), (100, 37, True), (300, 512, False),
+                                          (1000, 1024, True), (2048, 1500, False), (1, 5, False), (7, 1, True)])
+@pytest.mark.parametrize("p", [2, 3])
+def test_general_solver_against_cpu_oracle(shw, n, m, weighted, p):
+    """Loss and gradients of the general path against the torch restatement of the reference's bisection
+    (oracle/ref_mirror.py, pinned by the golden vectors), evaluated in float64 on the fp32 inputs."""
+    from oracle import ref_mirror
+    g = torch.Generator().manual_seed(5000 + n + 3 * m + p)
+    B, L = 2, 6
+    x, y, U = unit_cloud(g, B, n), unit_cloud(g, B, m), directions(g, B, L)
+    wu = wv = None
+    if weighted:
+        wu = torch.rand(n, generator=g) + 0.05
+        wv = torch.rand(m, generator=g) + 0.05
+        wu, wv = wu / wu.sum(), wv / wv.sum()
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, _ = shw.ssw_pair_losses(xs, ys, U.cuda(), p=p, return_slices=True,
+                                        u_weights=None if wu is None else wu.cuda(),
+                                        v_weights=None if wv is None else wv.cuda())
+    wts = torch.tensor([1.0, -0.5], device="cuda")
+    (pair * wts).sum().backward()
+    for b in range(B):
+        xd, yd = x[b].double().requires_grad_(True), y[b].double().requires_grad_(True)
+        ref = ref_mirror.per_slice_costs(xd, yd, U[b].double(), p=p,
+                                         u_weights=None if wu is None else wu.double(),
+                                         v_weights=None if wv is None else wv.double())
+        (ref.mean() * wts[b].item()).backward()
+        assert np.allclose(cost[b].detach().cpu().numpy(), ref.detach().numpy(), rtol=5e-5, atol=1e-9)
+        if min(n, m) >= 7:
+            grad_close(xs.grad[b].cpu().numpy(), xd.grad.numpy(), exact=(max(n, m) <= 128))
+            grad_close(ys.grad[b].cpu().numpy(), yd.grad.numpy(), exact=(max(n, m) <= 128))
+
+
+def test_general_solver_reduces_to_fast_path_on_equal_uniform_input(shw):
+    """n == m with explicitly uniform weights goes through the general solver and must agree with the
+    equal-size kernel (two different algorithms, same minimum)."""
+    g = torch.Generator().manual_seed(91)
+    x, y, U = unit_cloud(g, 2, 200).cuda(), unit_cloud(g, 2, 200).cuda(), directions(g, 2, 8).cuda()
+    w = torch.full((200,), 1.0 / 200, device="cuda")
+    fast = shw.ssw_pair_losses(x, y, U, p=2)
+    gen = shw.ssw_pair_losses(x, y, U, p=2, u_weights=w, v_weights=w)
+    assert torch.allclose(fast, gen, rtol=2e-5)
 
 
 # ------------------------------------------------------------------------------ golden: G6 headline shapes
@@ -340,7 +419,7 @@ def test_rejects_what_is_not_implemented_instead_of_falling_back(shw):
     with pytest.raises(RuntimeError):
         shw.sliced_cost(x.cpu(), x.cpu(), U.cpu())
     with pytest.raises(NotImplementedError):
-        shw.sliced_cost(x, x, U, u_weights=torch.ones(8, device="cuda") / 8)
+        shw.sliced_cost(x, x, U, p=1, u_weights=torch.ones(8, device="cuda") / 8)
     with pytest.raises(TypeError):
         shw.sliced_cost(x.double(), x.double(), U.double())
 
