@@ -61,7 +61,7 @@ def main():
                     help="replay the step as a hipGraph instead of launching eagerly (measured on MI355X: eager "
                          "0.352 ms/step vs replay 0.358 -- the step is one ~0.35 ms kernel plus one small one, so "
                          "replay's fixed cost outweighs the launch it saves; kept as an option)")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=2)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
