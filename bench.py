@@ -73,7 +73,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torchrun: always exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
@@ -89,18 +89,20 @@ def main():
     slice_cost = torch.empty(B * L, dtype=torch.float32, device=device)
     slice_shift = torch.empty(B * L, dtype=torch.int32, device=device)
     pair_loss = torch.empty(B, dtype=torch.float32, device=device)
-    total = torch.empty(2, dtype=torch.float32, device=device)
+    totals = [torch.empty(2, dtype=torch.float32, device=device) for _ in range(2)]   # ring: see step()
+    total = totals[0]
 
     if args.mode != "forward":
         return side_modes(args, shw_amd, x, y, U, device, rank)
 
-    def enqueue_loss():
+    def enqueue_loss(out=None):
         """The hot path: every kernel of one loss evaluation, enqueued on torch's current HIP stream."""
+        out = total if out is None else out
         st = torch.cuda.current_stream(device).cuda_stream
         _lib.check(lib.shw_ssw_forward(x.data_ptr(), y.data_ptr(), U.data_ptr(), B, N, N, L, L * 6, p,
                                        slice_cost.data_ptr(), slice_shift.data_ptr(), st), "shw_ssw_forward")
         _lib.check(lib.shw_ssw_reduce(slice_cost.data_ptr(), B, L, 1.0 / L, pair_loss.data_ptr(),
-                                      total.data_ptr(), st), "shw_ssw_reduce")
+                                      out.data_ptr(), st), "shw_ssw_reduce")
 
     graph = None
     if args.graph:
@@ -115,15 +117,32 @@ def main():
         with torch.cuda.graph(graph):
             enqueue_loss()
 
+    pending = [None, None]
+    counter = [0]
+
     def step():
-        if graph is not None:
-            graph.replay()
-        else:
-            enqueue_loss()
-        loss = total[0:1]
-        if dist is not None:
-            dist.all_reduce(loss)          # the one collective: scalar loss, sum over ranks (RCCL / xGMI)
+        """One loss evaluation.  Multi-GPU: the scalar all-reduce (the path's only collective, RCCL over xGMI)
+        is issued asynchronously on RCCL's stream and awaited one step later, so its ~40 us of launch latency
+        overlaps the next evaluation's kernels; results land in a two-deep ring of scalars."""
+        if dist is None:
+            if graph is not None:
+                graph.replay()
+            else:
+                enqueue_loss()
+            return total[0:1]
+        slot = counter[0] & 1
+        counter[0] += 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+        enqueue_loss(totals[slot])
+        loss = totals[slot][0:1]
+        pending[slot] = dist.all_reduce(loss, async_op=True)
         return loss
+
+    def drain():
+        for w in pending:
+            if w is not None:
+                w.wait()
 
     def fence():
         if dist is not None:
@@ -137,6 +156,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    if dist is not None:
+        drain()
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
