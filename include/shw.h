@@ -108,6 +108,25 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
                             float* slice_cost, float* slice_theta, float* coef_s, float* coef_t, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Euclidean sliced-Wasserstein (the notebooks' SWD baseline).
+ * Replaces: sliced_wasserstein_distance (Wasserstein_flow_problem/Flow_cube.ipynb:280-292): projection on unit
+ * directions, per-slice sort of both projected sequences, sum of |sorted difference|^p.
+ *   xs, xt (pairs, n, 3) -- equal counts, as the notebook code requires; thetas (slices, 3) shared
+ *   (theta_pair_stride = 0) or (pairs, slices, 3) (stride = slices*3); p >= 1; n <= 4096.
+ *   slice_sum (pairs*slices) out : S_l = sum_i |u_(i) - v_(i)|^p     (the notebook's outer (mean_l S_l)^(1/p)
+ *                                  is host arithmetic on `slices` numbers)
+ *   coef_s / coef_t (pairs*slices*n) scratch, both NULL for a value-only call : d S_l / d projection in
+ *   original point order; shw_esw_backward_points turns them into
+ *   grad_x[b,i,:] = sum_l slice_w[b,l] * coef[b,l,i] * theta[b,l,:]  (slice_w = upstream gradient of S).
+ */
+int shw_esw_forward(const float* xs, const float* xt, const float* thetas, int pairs, int n, int slices,
+                    long theta_pair_stride, float p, float* slice_sum, float* coef_s, float* coef_t, void* stream);
+
+int shw_esw_backward_points(const float* thetas, const float* coef_s, const float* coef_t, const float* slice_w,
+                            int pairs, int n, int slices, long theta_pair_stride,
+                            float* grad_xs, float* grad_xt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Chamfer distance (comparison baseline).
  * Replaces: pytorch3d.loss.chamfer_distance with default arguments, as called at
  * train_CD.py:123,161,327-328, main_rotation.py:203, test_ERROR.py:216 (third-party arithmetic,

@@ -32,6 +32,10 @@ _SIGNATURES = {
     "shw_ssw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                                ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "shw_esw_forward": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                       ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "shw_esw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_long, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_chamfer_forward": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32p,
                                            ctypes.c_void_p, _c_f32p, ctypes.c_void_p, _c_f32p, ctypes.c_void_p]),
     "shw_chamfer_backward": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p,

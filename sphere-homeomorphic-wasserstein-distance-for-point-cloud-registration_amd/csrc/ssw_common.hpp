@@ -54,26 +54,25 @@ __device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
 // circle coordinate of one projected point (reference :274-279):
 //     coord = (atan2(-b, -a) + pi) / (2 pi)
 // F.normalize (:274-275) is a positive rescale and cannot change the angle, so it is skipped.
-// atan2 is evaluated as atan(min/max) with a degree-17 odd minimax polynomial
-// (t + t^3 Q(t^2), |error| <= 7e-8 rad = 1.2 ulp on [0,1]) and octant fix-ups that follow the IEEE
+// atan2 is evaluated as atan(min/max) with a degree-15 odd minimax polynomial
+// (t + t^3 Q(t^2); with the 1.5-ulp quotient the total error is <= 1.9e-7 rad, rms 5.5e-8 rad, i.e.
+// <= 3e-8 in coordinate units = half an fp32 ulp of a coordinate in [0.5, 1)) and octant fix-ups that
+// follow the IEEE
 // signed-zero rules the reference relies on: a = b = +0 gives atan2(-0,-0) = -pi, i.e. coord 0.
 // Domain note: |a|,|b| below 1e-37 (denormal-scale projections) are treated as if max(|a|,|b|) were
 // 1e-37, i.e. the angle of such a vector is not resolved; exact zeros are handled exactly.
 __device__ __forceinline__ float circle_coord(float a, float b) {
   const float ax = fabsf(a), ay = fabsf(b);
   const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
-  const float rc = __builtin_amdgcn_rcpf(mx);
-  float t = mn * rc;
-  t = fmaf(fmaf(-mx, t, mn), rc, t);               // one Newton step: t = mn/mx to ~0.5 ulp
+  const float t = mn * __builtin_amdgcn_rcpf(mx);  // v_rcp_f32 (1 ulp) * mn: t = mn/mx to 1.5 ulp
   const float s = t * t;
-  float q = 2.6222439483e-03f;
-  q = fmaf(q, s, -1.5132533386e-02f);
-  q = fmaf(q, s, 4.1121855378e-02f);
-  q = fmaf(q, s, -7.3667056859e-02f);
-  q = fmaf(q, s, 1.0573931783e-01f);
-  q = fmaf(q, s, -1.4185975492e-01f);
-  q = fmaf(q, s, 1.9990396500e-01f);
-  q = fmaf(q, s, -3.3332985640e-01f);
+  float q = -4.3554045260e-03f;
+  q = fmaf(q, s, 2.3040132597e-02f);
+  q = fmaf(q, s, -5.7773582637e-02f);
+  q = fmaf(q, s, 9.7942344844e-02f);
+  q = fmaf(q, s, -1.3976581395e-01f);
+  q = fmaf(q, s, 1.9962704182e-01f);
+  q = fmaf(q, s, -3.3331659436e-01f);
   float r = fmaf(t * s, q, t);                     // atan(mn/mx) in [0, pi/4]
   r = (ay > ax) ? 1.57079637050628662f - r : r;    // angle from the x-axis, [0, pi/2]
   // x = -a is "negative" (incl. -0) exactly when the sign bit of a is clear

@@ -564,3 +564,37 @@ def test_reduce_paths_agree_and_match_torch(shw):
         assert torch.allclose(pl.double(), ref, rtol=1e-6)
         assert abs(tot[0].item() - ref.sum().item()) < 2e-6 * ref.sum().item()
         assert abs(tot[1].item() - ref.mean().item()) < 2e-6 * ref.mean().item()
+
+
+# ------------------------------------------------------------------------------ Euclidean sliced-W (notebook SWD)
+@pytest.mark.parametrize("n", [1, 50, 64, 1200, 2048, 4096])
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_euclidean_sliced_w_against_restatement(shw, n, p):
+    from oracle import euclid_sw
+    g = torch.Generator().manual_seed(600 + n + p)
+    L = 10
+    a, b = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g) * 0.7 + 0.2
+    th = shw.rand_projections(3, L)
+    xa, xb = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    sums = shw.esw_slice_sums(xa.unsqueeze(0), xb.unsqueeze(0), th.cuda(), p)
+    ad, bd = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = euclid_sw.slice_sums(ad, bd, th.double(), p)
+    assert np.allclose(sums[0].detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-9)
+    w = torch.rand(L, generator=g) + 0.5
+    (sums[0] * w.cuda()).sum().backward()
+    (ref * w.double()).sum().backward()
+    if p > 1 or n > 1:
+        grad_close(xa.grad.cpu().numpy(), ad.grad.numpy(), strict=5e-4)
+        grad_close(xb.grad.cpu().numpy(), bd.grad.numpy(), strict=5e-4)
+
+
+def test_euclidean_sliced_w_call_shape_and_rng(shw):
+    g = torch.Generator().manual_seed(7)
+    a, b = torch.randn(300, 3, generator=g).cuda(), torch.randn(300, 3, generator=g).cuda()
+    torch.manual_seed(11)
+    val = shw.sliced_wasserstein_distance(a, b, num_projection=50, p=2, device="cuda")
+    torch.manual_seed(11)
+    th = shw.rand_projections(3, 50)              # CPU generator, like the notebook cell
+    from oracle import euclid_sw
+    ref = euclid_sw.sliced_wasserstein_distance(a.cpu().double(), b.cpu().double(), th.double(), 2)
+    assert val.dim() == 0 and abs(val.item() - ref.item()) < 1e-5 * ref.item()
