@@ -145,6 +145,8 @@ def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weig
         raise ValueError("per-pair directions must be (B,L,3,2)")
     if not (float(p) >= 1.0):
         raise ValueError("p must be >= 1")
+    if Us.shape[-3] < 1 or Xs.shape[1] < 1 or Xt.shape[1] < 1:
+        raise ValueError("need at least one slice and one point per cloud")
     wu = _check_weights("u_weights", u_weights, Xs.shape[1], Xs.shape[0], Xs.device)
     wv = _check_weights("v_weights", v_weights, Xt.shape[1], Xs.shape[0], Xs.device)
     if (wu is not None or wv is not None) and float(p) == 1.0:
