@@ -36,6 +36,15 @@ int shw_abi_version(void);
 int shw_max_points(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Direction frames.
+ * Replaces: `U, _ = torch.linalg.qr(Z)` (max_spherical_sliced_w.py:308, _fast.py:318) for Z of shape (count, 3, 2):
+ * reduced QR by Householder reflectors with LAPACK's sign convention, one thread per matrix.  The Gaussian
+ * draw itself (`torch.randn`, :307) stays with the caller so the generator is consumed as in the reference.
+ *   z (count, 3, 2) fp32 in, u (count, 3, 2) fp32 out (orthonormal columns).
+ */
+int shw_stiefel_frames(const float* z, long count, float* u, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Spherical sliced-Wasserstein, forward.
  * Replaces: sliced_cost (max_spherical_sliced_w.py:251-286; batched _fast.py:258-295) =
  *   projection (:270-271) + normalise (:274-275) + circle coordinate (:278-279) + per-slice sort

@@ -17,6 +17,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "shw_abi_version": (ctypes.c_int, []),
     "shw_max_points": (ctypes.c_int, []),
+    "shw_stiefel_frames": (ctypes.c_int, [_c_f32p, ctypes.c_long, _c_f32p, ctypes.c_void_p]),
     "shw_ssw_forward": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_long, ctypes.c_float, _c_f32p, ctypes.c_void_p,
                                        ctypes.c_void_p]),

@@ -67,7 +67,9 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
   if (groups > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)groups;
   size_t lds = (size_t)WAVES * EPT * kWave * sizeof(float);
-  if (const char* extra = getenv("SHW_DEV_EXTRA_LDS")) lds += (size_t)atoi(extra);   // occupancy experiments only
+#ifdef SHW_DEV_OCCUPANCY_EXPERIMENT   // developer build only: pad the LDS request to lower the waves per CU
+  if (const char* extra = getenv("SHW_DEV_EXTRA_LDS")) lds += (size_t)atoi(extra);
+#endif
   const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
   const dim3 grid((unsigned)groups), block(WAVES * 64);
   if (A.p_int == 2) {

@@ -38,7 +38,25 @@ def draw_directions(num_projections, device, batch=None, d=3):
     _fast.py:317-318)."""
     shape = (num_projections, d, 2) if batch is None else (batch, num_projections, d, 2)
     Z = torch.randn(shape, device=device)
-    U, _ = torch.linalg.qr(Z)
+    return stiefel_frames(Z)
+
+
+def stiefel_frames(Z):
+    """Reduced QR `U, _ = torch.linalg.qr(Z)` of (..., 3, 2) Gaussian matrices.  On the device this is the HIP
+    kernel `shw_stiefel_frames` (LAPACK's Householder steps and sign convention, one thread per matrix):
+    torch.linalg.qr itself takes ~0.94 s for the 32 768 frames of config 3 on MI355X, and differs from the CPU
+    LAPACK result by up to 6e-6; the kernel takes microseconds and agrees with LAPACK to fp32 rounding.  CPU
+    tensors (tests of the generator stream) go through torch.linalg.qr."""
+    if not Z.is_cuda:
+        return torch.linalg.qr(Z)[0]
+    if Z.dtype != torch.float32 or tuple(Z.shape[-2:]) != (3, 2):
+        raise TypeError("stiefel_frames expects float32 (..., 3, 2)")
+    lib = _lib.load()
+    Zc = Z.contiguous()
+    U = torch.empty_like(Zc)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.shw_stiefel_frames(Zc.data_ptr(), Zc.numel() // 6, U.data_ptr(), _stream_ptr(Z.device)),
+                   "shw_stiefel_frames")
     return U
 
 

@@ -277,24 +277,42 @@ def test_g6_headline_shapes(shw, golden, tag):
 
 
 # ------------------------------------------------------------------------------ RNG stream parity (G5 on device)
-def test_direction_sampling_consumes_generator_like_reference(shw):
+def test_direction_sampling_consumes_generator_like_reference(shw, golden):
+    """Same generator consumption as the reference (:307, _fast.py:317); the frames come from the HIP
+    Householder kernel and must equal LAPACK's reduced QR of the same Gaussian matrices (sign convention
+    included) to fp32 rounding."""
     torch.manual_seed(777)
-    expect = torch.linalg.qr(torch.randn((24, 3, 2), device="cuda"))[0]      # reference :307-308
+    Z = torch.randn((24, 3, 2), device="cuda")                                # reference :307
     torch.manual_seed(777)
     got = shw.draw_directions(24, "cuda")
-    assert torch.equal(got, expect)
-    g = torch.Generator().manual_seed(5)
-    x, y = unit_cloud(g, 128).cuda(), unit_cloud(g, 128).cuda()
+    expect = torch.linalg.qr(Z.cpu().double())[0]
+    assert np.abs(got.cpu().double().numpy() - expect.numpy()).max() < 1e-6
+    gtg = torch.einsum("ldk,ldj->lkj", got, got).cpu()
+    assert np.abs(gtg.numpy() - np.eye(2)).max() < 1e-6                     # orthonormal columns
+    # fixture G5 (CPU generator): the kernel reproduces the frames the reference drew from the same Gaussians
+    g = golden("g5_rng.npz")
+    torch.manual_seed(int(g["seed"]))
+    Zc = torch.randn((24, 3, 2))
+    assert np.abs(shw.stiefel_frames(Zc.cuda()).cpu().numpy() - g["U_pair"]).max() < 1e-6
+    gen = torch.Generator().manual_seed(5)
+    x, y = unit_cloud(gen, 128).cuda(), unit_cloud(gen, 128).cuda()
     torch.manual_seed(777)
     val = shw.sliced_wasserstein_sphere(x, y, 24, "cuda", p=2)
-    assert rel(val.item(), shw.sliced_cost(x, y, expect, p=2).item()) == 0.0
-    xb, yb = unit_cloud(g, 3, 64).cuda(), unit_cloud(g, 3, 64).cuda()
+    assert rel(val.item(), shw.sliced_cost(x, y, got, p=2).item()) == 0.0
+    xb, yb = unit_cloud(gen, 3, 64).cuda(), unit_cloud(gen, 3, 64).cuda()
     torch.manual_seed(778)
-    expect_b = torch.linalg.qr(torch.randn((3, 12, 3, 2), device="cuda"))[0]  # _fast.py:317-318
+    expect_b = shw.stiefel_frames(torch.randn((3, 12, 3, 2), device="cuda"))     # _fast.py:317-318
     torch.manual_seed(778)
     valb = shw.sliced_wasserstein_sphere_fast(xb, yb, 12, "cuda", p=2)
     assert tuple(valb.shape) == (1,)
     assert rel(valb.item(), shw.sliced_cost(xb, yb, expect_b, p=2).item()) == 0.0
+    # degenerate columns: zero matrix, first column already on e1 -> still finite frames
+    Zd = torch.zeros(2, 3, 2, device="cuda")
+    Zd[1, 0, 0] = 2.0
+    Zd[1, 1, 1] = -3.0
+    Ud = shw.stiefel_frames(Zd)
+    assert torch.isfinite(Ud).all()
+    assert np.abs(Ud[1].cpu().numpy() - torch.linalg.qr(Zd[1].cpu())[0].numpy()).max() < 1e-6
 
 
 # ------------------------------------------------------------------------------ oracle on seeded inputs
@@ -598,3 +616,16 @@ def test_euclidean_sliced_w_call_shape_and_rng(shw):
     from oracle import euclid_sw
     ref = euclid_sw.sliced_wasserstein_distance(a.cpu().double(), b.cpu().double(), th.double(), 2)
     assert val.dim() == 0 and abs(val.item() - ref.item()) < 1e-5 * ref.item()
+
+
+# ------------------------------------------------------------------------------ trainer-level drop-in (config 5 shape)
+def test_config5_training_steps_reduce_the_loss(shw):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "config5_train_step.py")
+    spec = importlib.util.spec_from_file_location("config5_train_step", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses, _ = mod.run(batch=8, points=1024, slices=128, steps=25, verbose=False)
+    assert all(np.isfinite(losses))
+    assert min(losses[-5:]) < losses[0]
