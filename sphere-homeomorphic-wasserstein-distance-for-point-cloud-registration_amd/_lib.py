@@ -9,7 +9,7 @@ import subprocess
 import torch  # noqa: F401  (imported first on purpose: the process must hold ONE HIP runtime -- torch's)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshw_hip.so")
+LIB_PATH = os.environ.get("SHW_LIB_PATH") or os.path.join(_HERE, "libshw_hip.so")   # override: kernel A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _c_f32p = ctypes.c_void_p

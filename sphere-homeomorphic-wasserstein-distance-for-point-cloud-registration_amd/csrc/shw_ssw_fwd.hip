@@ -85,7 +85,10 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
 int dispatch_forward(SswArgs& A, hipStream_t stream) {
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT   // developer switch: compile a single size class quickly
-    case SHW_DEV_ONLY_EPT: return launch_forward<SHW_DEV_ONLY_EPT, (SHW_DEV_ONLY_EPT <= 32 ? 4 : (SHW_DEV_ONLY_EPT == 64 ? 2 : 1))>(A, stream);
+#ifndef SHW_DEV_FWD_WAVES
+#define SHW_DEV_FWD_WAVES (SHW_DEV_ONLY_EPT <= 32 ? 4 : (SHW_DEV_ONLY_EPT == 64 ? 2 : 1))
+#endif
+    case SHW_DEV_ONLY_EPT: return launch_forward<SHW_DEV_ONLY_EPT, SHW_DEV_FWD_WAVES>(A, stream);
 #else
     case 1: return launch_forward<1, 4>(A, stream);
     case 2: return launch_forward<2, 4>(A, stream);

@@ -629,3 +629,99 @@ def test_config5_training_steps_reduce_the_loss(shw):
     losses, _ = mod.run(batch=8, points=1024, slices=128, steps=25, verbose=False)
     assert all(np.isfinite(losses))
     assert min(losses[-5:]) < losses[0]
+
+
+# ------------------------------------------------------------------------------ hipGraph capture of the training step
+def test_loss_and_backward_capture_into_a_hip_graph(shw):
+    """Nothing on the path allocates through HIP, synchronises or reads back on the host, so forward + backward
+    of the loss can be captured once and replayed on new data (static input buffers)."""
+    g = torch.Generator().manual_seed(21)
+    B, N, L = 4, 512, 64
+    x_static = unit_cloud(g, B, N).cuda().requires_grad_(True)
+    y_static = unit_cloud(g, B, N).cuda()
+    U_static = shw.stiefel_frames(torch.randn(B, L, 3, 2, generator=g).cuda())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up on a side stream, as graph capture requires
+        for _ in range(2):
+            x_static.grad = None
+            shw.sliced_cost(x_static, y_static, U_static, p=2).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    x_static.grad = None
+    with torch.cuda.graph(graph):
+        loss_static = shw.sliced_cost(x_static, y_static, U_static, p=2)
+        loss_static.backward()
+    for seed in (1, 2):
+        h = torch.Generator().manual_seed(seed)
+        xn, yn = unit_cloud(h, B, N).cuda(), unit_cloud(h, B, N).cuda()
+        with torch.no_grad():
+            x_static.copy_(xn)
+            y_static.copy_(yn)
+        graph.replay()
+        torch.cuda.synchronize()
+        xe = xn.clone().requires_grad_(True)
+        le = shw.sliced_cost(xe, yn, U_static, p=2)
+        le.backward()
+        assert torch.equal(loss_static, le)
+        assert torch.equal(x_static.grad, xe.grad)
+
+
+# ------------------------------------------------------------------------------ API robustness
+def test_noncontiguous_inputs_partial_grads_and_shared_dirs(shw):
+    from oracle import exact_shift
+    g = torch.Generator().manual_seed(33)
+    B, n, L = 3, 96, 10
+    big = unit_cloud(g, B, 2 * n).cuda()
+    x = big[:, ::2, :]                                   # non-contiguous view
+    y = unit_cloud(g, B, n).cuda().requires_grad_(True)   # only the target requires grad
+    U = directions(g, L).cuda()                           # shared across pairs
+    assert not x.is_contiguous()
+    pair = shw.ssw_pair_losses(x, y, U, p=2)
+    pair.sum().backward()
+    assert y.grad is not None and torch.isfinite(y.grad).all()
+    for b in range(B):
+        ref = exact_shift.ssw_pair(x[b].cpu().numpy(), y[b].detach().cpu().numpy(), U.cpu().numpy(), 2)
+        assert abs(pair[b].item() - ref) < 1e-5 * ref
+        _, gy = exact_shift.ssw_pair_grad(x[b].cpu().numpy(), y[b].detach().cpu().numpy(), U.cpu().numpy(), 2)
+        grad_close(y.grad[b].cpu().numpy(), gy, exact=True)
+
+
+def test_no_grad_mode_single_slice_single_pair_and_fractional_power(shw):
+    from oracle import exact_shift
+    g = torch.Generator().manual_seed(34)
+    x, y, U = unit_cloud(g, 1, 300).cuda().requires_grad_(True), unit_cloud(g, 1, 300).cuda(), directions(g, 1, 1).cuda()
+    with torch.no_grad():
+        v = shw.sliced_cost(x, y, U, p=1.5)
+    assert not v.requires_grad and tuple(v.shape) == (1,)
+    ref = exact_shift.ssw_pair(x[0].detach().cpu().numpy(), y[0].cpu().numpy(), U[0].cpu().numpy(), 1.5)
+    assert abs(v.item() - ref) < 2e-5 * ref
+    with pytest.raises(ValueError):
+        shw.sliced_cost(x, y, U, p=0.5)
+    with pytest.raises(ValueError):
+        shw.ssw_pair_losses(x, y, U[:, :0], p=2)
+
+
+def test_many_slices_few_points_and_many_pairs(shw):
+    g = torch.Generator().manual_seed(35)
+    x, y, U = unit_cloud(g, 2, 16).cuda(), unit_cloud(g, 2, 16).cuda(), directions(g, 2, 4096).cuda()
+    pair, cost, _ = shw.ssw_pair_losses(x, y, U, p=2, return_slices=True)
+    assert torch.allclose(pair, cost.double().mean(1).float(), rtol=2e-6)
+    xb, yb, Ub = unit_cloud(g, 700, 64).cuda(), unit_cloud(g, 700, 64).cuda(), directions(g, 4).cuda()
+    pb, cb, _ = shw.ssw_pair_losses(xb, yb, Ub, p=2, return_slices=True)       # > 256 pairs: two-kernel reduction
+    assert torch.allclose(pb, cb.double().mean(1).float(), rtol=2e-6)
+    assert abs(shw.sliced_cost(xb, yb, Ub.unsqueeze(0).expand(700, -1, -1, -1).contiguous(), p=2).item()
+               - pb.double().sum().item()) < 1e-5 * pb.sum().item()
+
+
+def test_results_are_deterministic_run_to_run(shw):
+    g = torch.Generator().manual_seed(36)
+    x, y, U = unit_cloud(g, 8, 1000).cuda(), unit_cloud(g, 8, 1000).cuda(), directions(g, 8, 64).cuda()
+    outs = []
+    for _ in range(3):
+        xs = x.clone().requires_grad_(True)
+        v = shw.sliced_cost(xs, y, U, p=2)
+        v.backward()
+        outs.append((v.clone(), xs.grad.clone()))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
