@@ -725,3 +725,38 @@ def test_results_are_deterministic_run_to_run(shw):
         v.backward()
         outs.append((v.clone(), xs.grad.clone()))
     assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+
+
+# ------------------------------------------------------------------------------ the C ABI without Python
+def test_standalone_c_consumer_of_the_abi(shw, tmp_path):
+    """Compiles tests/capi/standalone.cpp with hipcc against include/shw.h + libshw_hip.so (system HIP runtime,
+    no torch in the process) and compares its output with the Python mirror on the same inputs."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(shw._lib.LIB_PATH)
+    exe = str(tmp_path / "standalone")
+    subprocess.run([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "capi", "standalone.cpp"),
+                    "-L", libdir, "-lshw_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True, capture_output=True)
+    g = torch.Generator().manual_seed(404)
+    B, n, L = 3, 500, 20
+    x, y, U = unit_cloud(g, B, n), unit_cloud(g, B, n), directions(g, B, L)
+    blob = str(tmp_path / "in.bin")
+    with open(blob, "wb") as fh:
+        fh.write(struct.pack("iii", B, n, L))
+        for t in (x, y, U):
+            fh.write(t.contiguous().numpy().astype(np.float32).tobytes())
+    out = subprocess.run([exe, blob], check=True, capture_output=True, text=True).stdout.split("\n")
+    pair = shw.ssw_pair_losses(x.cuda(), y.cuda(), U.cuda(), p=2).cpu().numpy()
+    cham = shw.chamfer_pair_losses(x.cuda(), y.cuda()).cpu().numpy()
+    tot = [float(v) for v in out[0].split()[1:]]
+    assert abs(tot[0] - pair.astype(np.float64).sum()) < 2e-6 * pair.sum()
+    for b in range(B):
+        _, _, p_c, c_c = out[1 + b].split()
+        assert float(p_c) == pytest.approx(float(pair[b]), rel=1e-7)
+        assert float(c_c) == pytest.approx(float(cham[b]), rel=1e-7)
