@@ -136,6 +136,27 @@ int shw_esw_backward_points(const float* thetas, const float* coef_s, const floa
                             float* grad_xs, float* grad_xt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Log-domain Sinkhorn distance (comparison metric; forward only).
+ * Replaces: log_Sinkhorn_Distance_Loss.forward and log_N_Sinkhorn_Distance_Loss.forward
+ * (/root/reference/Comparison_Wasserstein_with_Chamfer_distance/losses/sinkhorn.py:14-63, :104-157), called at
+ * main_rotation.py:207-211.
+ *   x (pairs, n, 3), y (pairs, m, 3); eps > 0; max_iter >= 0; norm_p = p of the coordinate-wise cost
+ *   sum_d |x_d - y_d|^p ('L2' -> 2); cost_pow = N of the log_N variant (1 for the plain class);
+ *   thresh = the convergence threshold on mean_b sum_i |u - u_old| (the reference hard-codes 1e-9).
+ *   workspace : shw_sinkhorn_workspace_bytes(pairs, n, m) bytes of device memory (duals, statistics);
+ *               after the call its first pairs*n floats hold u and the next pairs*m floats hold v.
+ *   cost (pairs) out : sum_ij exp(M_ij) C_ij  (before the batch reduction and the 1/N power, host side);
+ *   plan, cost_matrix : optional dense (pairs, n, m) outputs P and C that the reference returns; NULL to skip.
+ * The cost matrix is never stored unless asked for; the iteration count is fixed at enqueue time and the
+ * convergence test is a device-side flag that turns the remaining launches into no-ops (no host sync).
+ */
+size_t shw_sinkhorn_workspace_bytes(int pairs, int n, int m);
+
+int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
+                         int norm_p, int cost_pow, float thresh, void* workspace, float* cost, float* plan,
+                         float* cost_matrix, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Chamfer distance (comparison baseline).
  * Replaces: pytorch3d.loss.chamfer_distance with default arguments, as called at
  * train_CD.py:123,161,327-328, main_rotation.py:203, test_ERROR.py:216 (third-party arithmetic,

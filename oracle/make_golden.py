@@ -197,6 +197,28 @@ def main():
         out[f"value_{tag}_p2"] = _np(ref_fast.sliced_cost(xb, yb, Ub, p=2))
     np.savez_compressed(os.path.join(OUT, "g6_headline_shapes.npz"), **out)
 
+    # ---- G7: log-domain Sinkhorn (the reference class, importable: needs only torch) --------------
+    sk = _load("ref_sinkhorn", "/root/reference/Comparison_Wasserstein_with_Chamfer_distance/losses/sinkhorn.py")
+    g = torch.Generator().manual_seed(20250107)
+    xs = F.normalize(torch.randn(2, 96, 3, generator=g), dim=-1)
+    ys = xs @ rot_x(30).T + 0.05 * torch.randn(2, 96, 3, generator=g)
+    ys = ys[:, :80].contiguous()
+    out = {"x": _np(xs), "y": _np(ys)}
+    for eps, iters in ((0.05, 60), (0.01, 100)):
+        crit = sk.log_Sinkhorn_Distance_Loss(eps=eps, max_iter=iters, batch_reduction="none", type_of_cost_norm="L2")
+        cost, P, C = crit(xs, ys, "cpu")
+        tag = f"eps{eps}_it{iters}"
+        out[f"cost_{tag}"] = _np(cost)
+        out[f"P_rowsum_{tag}"] = _np(P.sum(-1))
+        out[f"P_colsum_{tag}"] = _np(P.sum(-2))
+    crit = sk.log_Sinkhorn_Distance_Loss(eps=0.05, max_iter=60, batch_reduction="sum", type_of_cost_norm="L1")
+    out["cost_L1_sum"] = _np(crit(xs, ys, "cpu")[0])
+    critN = sk.log_N_Sinkhorn_Distance_Loss(eps=0.05, max_iter=60, batch_reduction="mean", type_of_cost_norm="L2",
+                                            type_of_Wasserstein_N="2")
+    out["cost_N2_mean"] = _np(critN(xs, ys, "cpu")[0])
+    out["C_first_row"] = _np(C[0, 0])
+    np.savez_compressed(os.path.join(OUT, "g7_sinkhorn.npz"), **out)
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -178,3 +178,19 @@ def test_g6_headline_shapes(golden, tag):
         for p in (1, 2):
             per = ref_mirror.per_slice_costs(x[b], y[b], U[b], p=p).numpy()
             assert np.allclose(per, g[f"per_slice_{tag}_p{p}"][b], rtol=2e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------- G7: log-domain Sinkhorn
+@pytest.mark.parametrize("eps,iters", [(0.05, 60), (0.01, 100)])
+def test_g7_sinkhorn_mirror(golden, eps, iters):
+    from oracle import sinkhorn_mirror
+    g = golden("g7_sinkhorn.npz")
+    cost, P, C, _ = sinkhorn_mirror.sinkhorn_costs(T(g["x"]), T(g["y"]), eps, iters)
+    tag = f"eps{eps}_it{iters}"
+    assert rel(cost.numpy(), g[f"cost_{tag}"]) < 2e-5
+    assert np.allclose(P.sum(-1).numpy(), g[f"P_rowsum_{tag}"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(C[0, 0].numpy(), g["C_first_row"], rtol=1e-6)
+    l1, _, _, _ = sinkhorn_mirror.sinkhorn_costs(T(g["x"]), T(g["y"]), 0.05, 60, norm_p=1)
+    assert rel(l1.sum().numpy(), g["cost_L1_sum"]) < 2e-5
+    n2, _, _, _ = sinkhorn_mirror.sinkhorn_costs(T(g["x"]), T(g["y"]), 0.05, 60, cost_pow=2)
+    assert rel(n2.pow(0.5).mean().numpy(), g["cost_N2_mean"]) < 2e-5

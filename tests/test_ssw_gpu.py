@@ -760,3 +760,60 @@ def test_standalone_c_consumer_of_the_abi(shw, tmp_path):
         _, _, p_c, c_c = out[1 + b].split()
         assert float(p_c) == pytest.approx(float(pair[b]), rel=1e-7)
         assert float(c_c) == pytest.approx(float(cham[b]), rel=1e-7)
+
+
+# ------------------------------------------------------------------------------ log-domain Sinkhorn (forward)
+@pytest.mark.parametrize("eps,iters", [(0.05, 60), (0.01, 100)])
+def test_g7_sinkhorn_against_reference_fixture(shw, golden, eps, iters):
+    """eps divides every exponent, so fp32 rounding of the duals is amplified by 1/eps in the plan: the reference's
+    own fp32-vs-fp64 difference is ~1e-5 at eps = 0.05 and ~1e-4 at eps = 0.01; tolerance 5e-4 on the cost."""
+    g = golden("g7_sinkhorn.npz")
+    crit = shw.log_Sinkhorn_Distance_Loss(eps=eps, max_iter=iters, batch_reduction="none", type_of_cost_norm="L2")
+    cost, P, C = crit(dev(g["x"]), dev(g["y"]), "cuda")
+    tag = f"eps{eps}_it{iters}"
+    assert tuple(P.shape) == (2, 96, 80) and tuple(C.shape) == (2, 96, 80)
+    assert rel(cost.cpu().numpy(), g[f"cost_{tag}"]) < 5e-4
+    assert np.allclose(P.sum(-1).cpu().numpy(), g[f"P_rowsum_{tag}"], rtol=2e-3, atol=1e-6)
+    assert np.allclose(P.sum(-2).cpu().numpy(), g[f"P_colsum_{tag}"], rtol=2e-3, atol=1e-6)
+    assert np.allclose(C[0, 0].cpu().numpy(), g["C_first_row"], rtol=1e-6)
+    assert abs((P * C).sum((-2, -1))[0].item() - cost[0].item()) < 1e-5 * cost[0].item()
+
+
+def test_g7_sinkhorn_variants_and_call_shapes(shw, golden):
+    g = golden("g7_sinkhorn.npz")
+    x, y = dev(g["x"]), dev(g["y"])
+    l1 = shw.log_Sinkhorn_Distance_Loss(0.05, 60, batch_reduction="sum", type_of_cost_norm="L1", return_plan=False)
+    val, P, C = l1(x, y, "cuda")
+    assert P is None and C is None and val.dim() == 0
+    assert rel(val.item(), g["cost_L1_sum"]) < 5e-4
+    n2 = shw.log_N_Sinkhorn_Distance_Loss(0.05, 60, batch_reduction="mean", type_of_cost_norm="L2",
+                                          type_of_Wasserstein_N="2", return_plan=False)
+    assert rel(n2(x, y, "cuda")[0].item(), g["cost_N2_mean"]) < 5e-4
+    single = shw.log_Sinkhorn_Distance_Loss(0.05, 10)(x[0], y[0], "cuda")
+    assert single[0].dim() == 0 and tuple(single[1].shape) == (96, 80)
+    with pytest.raises(NotImplementedError):
+        shw.log_Sinkhorn_Distance_Loss(0.05, 10)(x.clone().requires_grad_(True), y, "cuda")
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (5, 700), (300, 257), (1024, 1024)])
+def test_sinkhorn_sizes_against_restatement(shw, n, m):
+    from oracle import sinkhorn_mirror
+    g = torch.Generator().manual_seed(70 + n + m)
+    B = 2
+    x, y = unit_cloud(g, B, n), unit_cloud(g, B, m) * 0.9 + 0.05
+    iters = 30
+    cost, _, _ = shw.sinkhorn_pair_costs(x.cuda(), y.cuda(), 0.05, iters)
+    ref, _, _, _ = sinkhorn_mirror.sinkhorn_costs(x.double(), y.double(), 0.05, iters)
+    assert rel(cost.cpu().numpy(), ref.numpy()) < 5e-4
+
+
+def test_sinkhorn_convergence_flag_stops_the_iteration(shw):
+    """Identical tiny clouds converge immediately; with a loose threshold the device-side flag must freeze the
+    duals exactly where the reference's `break` would (same result as running fewer iterations)."""
+    g = torch.Generator().manual_seed(3)
+    x = unit_cloud(g, 2, 32).cuda()
+    from oracle import sinkhorn_mirror
+    ref, _, _, its = sinkhorn_mirror.sinkhorn_costs(x.cpu().double(), x.cpu().double(), 0.5, 200, thresh=1e-3)
+    assert its < 200
+    got, _, _ = shw.sinkhorn_pair_costs(x, x.clone(), 0.5, 200, thresh=1e-3)
+    assert rel(got.cpu().numpy(), ref.numpy()) < 5e-4
