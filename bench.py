@@ -32,6 +32,33 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def next_pow2(v):
+    r = 1
+    while r < v:
+        r <<= 1
+    return max(r, 64)
+
+
+def stages(n):
+    k = next_pow2(n).bit_length() - 1
+    return k * (k + 1) // 2
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its communicator is created; the contract is ONE JSON line on
+    stdout, so file descriptor 1 points at stderr while the process group and its first collectives come up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def make_inputs(B, N, L, rank, device):
     """host-generated, seeded, unit-normalised Gaussian clouds, explicit directions."""
     def cloud(seed):
@@ -76,7 +103,12 @@ def main():
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torchrun: always exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)                                # creates the communicator (and its banner) now
+            dist.barrier()
+            torch.cuda.synchronize(device)
 
     import shw_amd
     lib = shw_amd._lib.load()
@@ -156,10 +188,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0
     if dist is not None:
         drain()
+    torch.cuda.synchronize(device)
+    t_sync = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    print("[bench] enqueue %.2f ms, device done %.2f ms, after barrier %.2f ms" % (1e3 * t_enq, 1e3 * t_sync, 1e3 * elapsed),
+          file=sys.stderr, flush=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,9 +227,10 @@ def main():
         "loss": loss_value,
     }
 
-    if world == 1:
-        # ---- roofline of the dominant kernel (ssw_forward_kernel), HIP events on the launch stream
-        reps = max(10, args.steps)
+    if True:
+        # ---- roofline of the dominant kernel (ssw_forward_kernel), HIP events on the launch stream;
+        #      per GPU (every rank measures its own launches, rank 0's figure is reported)
+        reps = max(10, min(args.steps, 200))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(reps):
@@ -216,13 +254,19 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": float(traffic) if traffic else None,
-            "kernel": "ssw_forward_kernel<32,4,2,true>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
+            "kernel": "ssw_forward_kernel<32,4,2,true>" if (N, p) == (2048, 2.0) else "ssw_forward_kernel",
+            "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
+            "secondary_model": {"unit": "compare-exchanges/s", "achieved": B * L * 2 * (next_pow2(N) // 2) * stages(N) / (kernel_ms * 1e-3),
+                                "note": "two bitonic sorts of next_pow2(N) keys per slice; the VALU/LDS-crossbar price "
+                                        "list in DESIGN.md section 4 puts the bound at ~0.245 ms per launch at config 3"},
             "note": "compulsory HBM traffic is 0.06 B/point-pair: the kernel is VALU/LDS-crossbar bound (in-register "
                     "bitonic sort), not HBM bound; see DESIGN.md for the compare-exchange model",
             "point_pairs_per_s_kernel_only": B * N * L / (kernel_ms * 1e-3),
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, y, U, p, args.cpu_sample_pairs)
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0:
         print(json.dumps(out), flush=True)
