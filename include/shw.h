@@ -135,6 +135,12 @@ int shw_esw_backward_points(const float* thetas, const float* coef_s, const floa
                             int pairs, int n, int slices, long theta_pair_stride,
                             float* grad_xs, float* grad_xt, void* stream);
 
+/* Gradient w.r.t. the directions (max_sliced_wasserstein_distance, Flow_cube.ipynb:294-323, ascends on them):
+ *   grad_thetas[b,l,:] = slice_w[b,l] * sum_i (coef_s[b,l,i] * xs[b,i,:] + coef_t[b,l,i] * xt[b,i,:]),
+ * always (pairs, slices, 3); directions shared by several pairs sum their rows on the host side. */
+int shw_esw_backward_dirs(const float* xs, const float* xt, const float* coef_s, const float* coef_t,
+                          const float* slice_w, int pairs, int n, int slices, float* grad_thetas, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Log-domain Sinkhorn distance (comparison metric; forward only).
  * Replaces: log_Sinkhorn_Distance_Loss.forward and log_N_Sinkhorn_Distance_Loss.forward

@@ -4,7 +4,7 @@ Importable as `importlib.import_module("sphere-homeomorphic-wasserstein-distance
 or through the top-level alias module `shw_amd`."""
 from . import _lib, dist
 from .chamfer import chamfer_distance, chamfer_pair_losses
-from .esw import esw_slice_sums, rand_projections, sliced_wasserstein_distance
+from .esw import esw_slice_sums, max_sliced_wasserstein_distance, rand_projections, sliced_wasserstein_distance
 from .modules import (ChamferCriterion, SlicedSphereW, SSWCriterion, max_spherical_wassersten_distance,
                       max_spherical_wassersten_distance_fast)
 from .sinkhorn import log_N_Sinkhorn_Distance_Loss, log_Sinkhorn_Distance_Loss, sinkhorn_pair_costs

@@ -37,6 +37,8 @@ _SIGNATURES = {
                                        ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_esw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_long, _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "shw_esw_backward_dirs": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, _c_f32p, ctypes.c_void_p]),
     "shw_sinkhorn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "shw_sinkhorn_forward": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,

@@ -152,6 +152,41 @@ __global__ __launch_bounds__(256) void esw_backward_points_kernel(const float* _
   if (i < n) { G[3 * i] = gx; G[3 * i + 1] = gy; G[3 * i + 2] = gz; }
 }
 
+// grad_theta[b,l,:] = w[b,l] * sum_i ( coef_s[b,l,i] * xs[b,i,:] + coef_t[b,l,i] * xt[b,i,:] )
+// (the projections are x . theta, so d S_l / d theta is the coefficient-weighted sum of the points; used by
+// the notebooks' max-sliced-W, which ascends on the direction).  One workgroup per (slice, pair), fixed-order tree.
+__global__ __launch_bounds__(256) void esw_backward_dirs_kernel(const float* __restrict__ xs,
+                                                                const float* __restrict__ xt,
+                                                                const float* __restrict__ coef_s,
+                                                                const float* __restrict__ coef_t,
+                                                                const float* __restrict__ slice_w, int n, int slices,
+                                                                float* __restrict__ grad_thetas) {
+  __shared__ float red[3][4];
+  const int l = blockIdx.x, b = blockIdx.y;
+  const float* Xs = xs + (long)b * n * 3;
+  const float* Xt = xt + (long)b * n * 3;
+  const float* Cs = coef_s + ((long)b * slices + l) * n;
+  const float* Ct = coef_t + ((long)b * slices + l) * n;
+  float g[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float cs = Cs[i], ct = Ct[i];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[d] = fmaf(cs, Xs[3 * i + d], fmaf(ct, Xt[3 * i + d], g[d]));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float v = wave_sum(g[d], lane);
+    if (lane == 0) red[d][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    grad_thetas[((long)b * slices + l) * 3 + d] =
+        ((red[d][0] + red[d][1]) + (red[d][2] + red[d][3])) * slice_w[(long)b * slices + l];
+  }
+}
+
 template <int EPT, int WAVES>
 static int launch_esw(EswArgs& A, hipStream_t stream) {
   const long total = (long)A.pairs * A.slices;
@@ -208,6 +243,16 @@ int shw_esw_backward_points(const float* thetas, const float* coef_s, const floa
   const int chunks = (n + 255) / 256;
   hipLaunchKernelGGL(shw::esw_backward_points_kernel, dim3(2 * chunks, pairs), dim3(256), 0, (hipStream_t)stream,
                      thetas, coef_s, coef_t, slice_w, n, slices, theta_pair_stride, grad_xs, grad_xt, chunks);
+  return (int)hipGetLastError();
+}
+
+int shw_esw_backward_dirs(const float* xs, const float* xt, const float* coef_s, const float* coef_t,
+                          const float* slice_w, int pairs, int n, int slices, float* grad_thetas, void* stream) {
+  if (!xs || !xt || !coef_s || !coef_t || !slice_w || !grad_thetas) return (int)hipErrorInvalidValue;
+  if (pairs < 0 || pairs > 65535 || slices < 0 || n < 1) return (int)hipErrorInvalidValue;
+  if (pairs == 0 || slices == 0) return 0;
+  hipLaunchKernelGGL(shw::esw_backward_dirs_kernel, dim3(slices, pairs), dim3(256), 0, (hipStream_t)stream, xs, xt,
+                     coef_s, coef_t, slice_w, n, slices, grad_thetas);
   return (int)hipGetLastError();
 }
 

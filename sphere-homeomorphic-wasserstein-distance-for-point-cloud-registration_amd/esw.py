@@ -9,8 +9,8 @@ Notes on the reference cell: it draws the directions on the CPU generator and mo
 instead of its own `num_projection` argument (a notebook slip) -- here the argument is used.  The notebook cannot
 be imported (its `datas` / `losses` modules are not shipped), so this baseline is pinned by the restatement in
 oracle/euclid_sw.py only: PARITY UNPINNED by reference fixtures.
-`max_sliced_wasserstein_distance` (gradient ascent on the direction) is not provided: the op is differentiable
-w.r.t. the clouds, not the directions."""
+`max_sliced_wasserstein_distance` (:294-323: Adam ascent on ONE direction, then the distance along it) is mirrored
+too; the op is differentiable w.r.t. the clouds and the directions."""
 from __future__ import annotations
 
 import torch
@@ -34,7 +34,7 @@ class _SliceSums(torch.autograd.Function):
         xs, xt, th = Xs.contiguous(), Xt.contiguous(), thetas.contiguous()
         stride = 0 if th.dim() == 2 else L * 3
         sums = torch.empty(B * L, dtype=torch.float32, device=dev)
-        need = Xs.requires_grad or Xt.requires_grad
+        need = Xs.requires_grad or Xt.requires_grad or thetas.requires_grad
         cs = ct = None
         if need:
             cs = torch.empty(B * L * n, dtype=torch.float32, device=dev)
@@ -44,24 +44,34 @@ class _SliceSums(torch.autograd.Function):
                                            sums.data_ptr(), cs.data_ptr() if need else None,
                                            ct.data_ptr() if need else None, _stream_ptr(dev)), "shw_esw_forward")
         if need:
-            ctx.save_for_backward(th, cs, ct)
+            ctx.save_for_backward(th, cs, ct, xs, xt)
             ctx.dims = (B, n, L, stride)
+            ctx.theta_shape = tuple(thetas.shape)
         return sums.view(B, L)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        th, cs, ct = ctx.saved_tensors
+        th, cs, ct, xs, xt = ctx.saved_tensors
         B, n, L, stride = ctx.dims
         dev = th.device
-        gxs = torch.empty(B, n, 3, dtype=torch.float32, device=dev)
-        gxt = torch.empty(B, n, 3, dtype=torch.float32, device=dev)
+        gxs = gxt = gth = None
         w = g.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
-            _lib.check(lib.shw_esw_backward_points(th.data_ptr(), cs.data_ptr(), ct.data_ptr(), w.data_ptr(), B, n, L,
-                                                   stride, gxs.data_ptr(), gxt.data_ptr(), _stream_ptr(dev)),
-                       "shw_esw_backward_points")
-        return gxs, gxt, None, None
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                gxs = torch.empty(B, n, 3, dtype=torch.float32, device=dev)
+                gxt = torch.empty(B, n, 3, dtype=torch.float32, device=dev)
+                _lib.check(lib.shw_esw_backward_points(th.data_ptr(), cs.data_ptr(), ct.data_ptr(), w.data_ptr(), B, n,
+                                                       L, stride, gxs.data_ptr(), gxt.data_ptr(), _stream_ptr(dev)),
+                           "shw_esw_backward_points")
+            if ctx.needs_input_grad[2]:
+                gth = torch.empty(B, L, 3, dtype=torch.float32, device=dev)
+                _lib.check(lib.shw_esw_backward_dirs(xs.data_ptr(), xt.data_ptr(), cs.data_ptr(), ct.data_ptr(),
+                                                     w.data_ptr(), B, n, L, gth.data_ptr(), _stream_ptr(dev)),
+                           "shw_esw_backward_dirs")
+                if len(ctx.theta_shape) == 2:          # directions shared by the pairs
+                    gth = gth.sum(0)
+        return gxs, gxt, gth, None
 
 
 def esw_slice_sums(Xs, Xt, thetas, p=2):
@@ -72,11 +82,29 @@ def esw_slice_sums(Xs, Xt, thetas, p=2):
         raise ValueError("the Euclidean sliced distance needs two (B,n,3) clouds of equal size")
     if not thetas.is_cuda or thetas.dtype != torch.float32 or thetas.shape[-1] != 3:
         raise TypeError("thetas must be a float32 device tensor (L,3) or (B,L,3)")
-    return _SliceSums.apply(Xs, Xt, thetas.detach(), float(p))
+    return _SliceSums.apply(Xs, Xt, thetas, float(p))
 
 
 def sliced_wasserstein_distance(first_samples, second_samples, num_projection=100, p=2, device="cuda"):
     dim = second_samples.size(1)
     projections = rand_projections(dim, num_projection).to(device)
     sums = esw_slice_sums(first_samples.unsqueeze(0), second_samples.unsqueeze(0), projections, p)
+    return torch.pow(sums.mean(), 1.0 / p)
+
+
+def max_sliced_wasserstein_distance(first_samples, second_samples, num_projection=100, p=2, max_iter=10, device="cuda"):
+    """Flow_cube.ipynb:294-323: one direction, `max_iter` Adam ascent steps on it (lr 0.005, betas (0.999, 0.999),
+    re-normalised after every step) against the detached clouds, then the distance along the final direction."""
+    dim = second_samples.size(1)
+    first_d, second_d = first_samples.detach().unsqueeze(0), second_samples.detach().unsqueeze(0)
+    projections = rand_projections(dim, 1).to(device)
+    projections.requires_grad_()
+    optimizer = torch.optim.Adam([projections], lr=0.005, betas=(0.999, 0.999))
+    for _ in range(max_iter):
+        dist_l = torch.pow(esw_slice_sums(first_d, second_d, projections, p).mean(), 1.0 / p)
+        optimizer.zero_grad()
+        (-dist_l).backward()
+        optimizer.step()
+        projections.data = projections.data / torch.sqrt(torch.sum(projections.data ** 2, dim=1))
+    sums = esw_slice_sums(first_samples.unsqueeze(0), second_samples.unsqueeze(0), projections.detach(), p)
     return torch.pow(sums.mean(), 1.0 / p)

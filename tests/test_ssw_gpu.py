@@ -817,3 +817,36 @@ def test_sinkhorn_convergence_flag_stops_the_iteration(shw):
     assert its < 200
     got, _, _ = shw.sinkhorn_pair_costs(x, x.clone(), 0.5, 200, thresh=1e-3)
     assert rel(got.cpu().numpy(), ref.numpy()) < 5e-4
+
+
+def test_euclidean_sliced_w_direction_gradient_and_max_sw(shw):
+    from oracle import euclid_sw
+    g = torch.Generator().manual_seed(808)
+    n, L = 400, 6
+    a, b = torch.randn(2, n, 3, generator=g), torch.randn(2, n, 3, generator=g) * 0.6 + 0.3
+    th = shw.rand_projections(3, L)
+    tg = th.cuda().requires_grad_(True)
+    sums = shw.esw_slice_sums(a.cuda(), b.cuda(), tg, 2)
+    w = torch.rand(2, L, generator=g) + 0.5
+    (sums * w.cuda()).sum().backward()
+    td = th.double().requires_grad_(True)
+    ref = torch.stack([euclid_sw.slice_sums(a[k].double(), b[k].double(), td, 2) for k in range(2)])
+    (ref * w.double()).sum().backward()
+    assert np.allclose(sums.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5)
+    grad_close(tg.grad.cpu().numpy(), td.grad.numpy(), strict=1e-3, exact=True)
+    # max-sliced-W: the same Adam ascent (notebook cell :294-323) run on the CPU restatement in float64 from the
+    # same starting direction must land on the same value
+    x, y = a[0].cuda(), b[0].cuda()
+    torch.manual_seed(5)
+    d1 = shw.max_sliced_wasserstein_distance(x, y, p=2, max_iter=25, device="cuda").item()
+    torch.manual_seed(5)
+    proj = shw.rand_projections(3, 1).double().requires_grad_(True)
+    opt = torch.optim.Adam([proj], lr=0.005, betas=(0.999, 0.999))
+    for _ in range(25):
+        d = torch.pow(euclid_sw.slice_sums(a[0].double(), b[0].double(), proj, 2).mean(), 0.5)
+        opt.zero_grad()
+        (-d).backward()
+        opt.step()
+        proj.data = proj.data / torch.sqrt(torch.sum(proj.data ** 2, dim=1))
+    ref_d = torch.pow(euclid_sw.slice_sums(a[0].double(), b[0].double(), proj.detach(), 2).mean(), 0.5).item()
+    assert abs(d1 - ref_d) < 1e-3 * ref_d
