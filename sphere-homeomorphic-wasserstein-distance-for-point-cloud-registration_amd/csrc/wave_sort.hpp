@@ -85,6 +85,22 @@ __device__ __forceinline__ unsigned lane_xor(unsigned x, int lane) {
   return (unsigned)as_i(lane_xor<MASK>(as_f((int)x), lane));
 }
 
+// 64-bit items (key bits << 32 | original index); policy U64Items further down
+typedef unsigned long long item_t;
+
+__device__ __forceinline__ item_t make_item(float key, int idx) {
+  return ((item_t)(unsigned)as_i(key) << 32) | (unsigned)idx;
+}
+__device__ __forceinline__ float item_key(item_t it) { return as_f((int)(it >> 32)); }
+__device__ __forceinline__ int item_idx(item_t it) { return (int)(unsigned)it; }
+
+template <int MASK>
+__device__ __forceinline__ item_t lane_xor(item_t x, int lane) {
+  const float lo = lane_xor<MASK>(as_f((int)(unsigned)x), lane);
+  const float hi = lane_xor<MASK>(as_f((int)(x >> 32)), lane);
+  return ((item_t)(unsigned)as_i(hi) << 32) | (unsigned)as_i(lo);
+}
+
 template <class P>
 __device__ __forceinline__ void cmp_swap(typename P::type& lo, typename P::type& hi) {
   const typename P::type a = lo, b = hi;
@@ -166,100 +182,29 @@ __device__ __forceinline__ void wave_sort(unsigned (&x)[EPT], int lane) {
 
 // ---------------------------------------------------------------------------------------------
 // Key + payload variant: items are 64-bit words (float key bits << 32 | original index).  Keys are
-// non-negative floats (circle coordinates, +inf padding), whose bit patterns order like unsigned
-// integers, and the index makes every item unique, so the result is the STABLE ascending order of
-// the keys (ties by original index) -- the order torch.sort yields in the reference (:163-164).
-// Compare-exchanges cost one v_cmp_*_u64 and two v_cndmask per 64-bit item instead of one
-// v_min/v_max/v_med3, which is why the loss-only kernels use the key-only network above.
+// non-negative floats (circle coordinates, +inf padding) or order-preserving transforms of signed floats,
+// whose bit patterns order like unsigned integers, and the index makes every item unique, so the result is
+// the STABLE ascending order of the keys (ties by original index) -- the order torch.sort yields in the
+// reference (:163-164).  Same network, third key policy: a compare-exchange costs one v_cmp_*_u64 and two
+// v_cndmask per item instead of one v_min/v_max/v_med3, which is why the loss-only kernels sort bare keys
+// and the training kernel sorts packed 32-bit words (shw_ssw_grad.hip).
 // ---------------------------------------------------------------------------------------------
-typedef unsigned long long item_t;
-
-__device__ __forceinline__ item_t make_item(float key, int idx) {
-  return ((item_t)(unsigned)as_i(key) << 32) | (unsigned)idx;
-}
-__device__ __forceinline__ float item_key(item_t it) { return as_f((int)(it >> 32)); }
-__device__ __forceinline__ int item_idx(item_t it) { return (int)(unsigned)it; }
-
-template <int MASK>
-__device__ __forceinline__ item_t lane_xor_item(item_t x, int lane) {
-  const float lo = lane_xor<MASK>(as_f((int)(unsigned)x), lane);
-  const float hi = lane_xor<MASK>(as_f((int)(x >> 32)), lane);
-  return ((item_t)(unsigned)as_i(hi) << 32) | (unsigned)as_i(lo);
-}
-
-__device__ __forceinline__ void cmp_swap_item(item_t& lo, item_t& hi) {
-  const item_t a = lo, b = hi;
-  const bool sw = a > b;
-  lo = sw ? b : a;
-  hi = sw ? a : b;
-}
-
-template <int EPT, int J>
-__device__ __forceinline__ void lane_stages_kv(item_t (&x)[EPT]) {
-  if constexpr (J >= 1) {
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      if ((r & J) == 0) cmp_swap_item(x[r], x[r | J]);
-    }
-    lane_stages_kv<EPT, J / 2>(x);
+struct U64Items {
+  typedef item_t type;
+  static __device__ __forceinline__ item_t lo(item_t a, item_t b) { return a > b ? b : a; }
+  static __device__ __forceinline__ item_t hi(item_t a, item_t b) { return a > b ? a : b; }
+  static __device__ __forceinline__ item_t bound(bool upper) { return upper ? ~0ull : 0ull; }
+  // the lower lane keeps the smaller item, the upper lane the larger; items are unique: no tie case
+  static __device__ __forceinline__ item_t pick(item_t x, item_t p, item_t bnd) {
+    const bool take = (p < x) != (bnd != 0ull);
+    return take ? p : x;
   }
-}
-
-template <int EPT, int K>
-__device__ __forceinline__ void lane_merges_kv(item_t (&x)[EPT]) {
-  if constexpr (K <= EPT) {
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int q = r ^ (K - 1);
-      if (q > r) cmp_swap_item(x[r], x[q]);
-    }
-    lane_stages_kv<EPT, K / 4>(x);
-    lane_merges_kv<EPT, K * 2>(x);
-  }
-}
-
-// keep own item or take the partner's: the lower lane keeps the smaller, the upper lane the larger
-__device__ __forceinline__ item_t pick_item(item_t own, item_t other, bool upper) {
-  const bool take = (other < own) != upper;       // items are unique: no tie case
-  return take ? other : own;
-}
-
-template <int EPT, int M>
-__device__ __forceinline__ void xlane_stages_kv(item_t (&x)[EPT], int lane) {
-  if constexpr (M >= 1) {
-    const bool upper = (lane & M) != 0;
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) x[r] = pick_item(x[r], lane_xor_item<M>(x[r], lane), upper);
-    xlane_stages_kv<EPT, M / 2>(x, lane);
-  }
-}
-
-template <int EPT, int C>
-__device__ __forceinline__ void xlane_merges_kv(item_t (&x)[EPT], int lane) {
-  if constexpr (C <= 6) {
-    constexpr int MASK = (1 << C) - 1;
-    const bool upper = (lane & (1 << (C - 1))) != 0;
-    if constexpr (EPT == 1) {
-      x[0] = pick_item(x[0], lane_xor_item<MASK>(x[0], lane), upper);
-    } else {
-#pragma unroll
-      for (int r = 0; r < EPT / 2; ++r) {
-        const item_t pa = lane_xor_item<MASK>(x[EPT - 1 - r], lane);
-        const item_t pb = lane_xor_item<MASK>(x[r], lane);
-        x[r] = pick_item(x[r], pa, upper);
-        x[EPT - 1 - r] = pick_item(x[EPT - 1 - r], pb, upper);
-      }
-    }
-    xlane_stages_kv<EPT, (1 << C) / 4>(x, lane);
-    lane_stages_kv<EPT, EPT / 2>(x);
-    xlane_merges_kv<EPT, C + 1>(x, lane);
-  }
-}
+};
 
 template <int EPT>
 __device__ __forceinline__ void wave_sort_kv(item_t (&x)[EPT], int lane) {
-  lane_merges_kv<EPT, 2>(x);
-  xlane_merges_kv<EPT, 1>(x, lane);
+  lane_merges<U64Items, EPT, 2>(x);
+  xlane_merges<U64Items, EPT, 1>(x, lane);
 }
 
 // ----- wave-wide sums (result valid in every lane) ---------------------------------------------
