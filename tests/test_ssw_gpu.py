@@ -850,3 +850,39 @@ def test_euclidean_sliced_w_direction_gradient_and_max_sw(shw):
         proj.data = proj.data / torch.sqrt(torch.sum(proj.data ** 2, dim=1))
     ref_d = torch.pow(euclid_sw.slice_sums(a[0].double(), b[0].double(), proj.detach(), 2).mean(), 0.5).item()
     assert abs(d1 - ref_d) < 1e-3 * ref_d
+
+
+# ------------------------------------------------------------------------------ bench.py contract
+def _run_bench(extra, torchrun=False):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable]
+    if torchrun:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29533"]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"] + extra
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, cwd=root).stdout.strip().split("\n")
+    assert len(out) == 1, out                      # exactly ONE line on stdout
+    return json.loads(out[0])
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    d = _run_bench(["--cpu-sample-pairs", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["value"] > 1e3 * c["value"]          # sanity: orders of magnitude above the CPU restatement
+
+
+def test_bench_under_torchrun_uses_rccl_and_still_prints_one_line():
+    d = _run_bench(["--no-cpu-baseline"], torchrun=True)
+    assert d["n_gpus"] == 1 and "roofline" in d and "cpu_baseline" not in d
