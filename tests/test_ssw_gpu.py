@@ -886,3 +886,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 def test_bench_under_torchrun_uses_rccl_and_still_prints_one_line():
     d = _run_bench(["--no-cpu-baseline"], torchrun=True)
     assert d["n_gpus"] == 1 and "roofline" in d and "cpu_baseline" not in d
+
+
+def test_dist_module_over_rccl_with_the_hip_evaluator():
+    """dist.py with its default (HIP) local evaluator over the nccl backend, world size 1 (one GPU per box; the
+    world_size-2 logic is covered by tests/test_dist_gloo.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29544", os.path.join(root, "tests", "helpers", "dist_nccl_worker.py")]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=root)
+    assert res.returncode == 0 and "DIST_NCCL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
