@@ -100,11 +100,12 @@ int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
                             float* grad_xs, float* grad_xt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Spherical sliced-Wasserstein, general circular OT for p != 1: n != m and / or non-uniform weights.
+ * Spherical sliced-Wasserstein, general circular OT: n != m and / or non-uniform weights.
  * Replaces: binary_search_circle with u_weights / v_weights and unequal sample counts
  * (max_spherical_sliced_w.py:117-207, dCost :25-65, Cost :68-113), reached from sliced_cost (:284) when the
  * trainers use different source / target densities (train_W_COS.py:292-293,334-336) or the caller passes
- * weights (:289).  Follows the reference's bisection over the cut theta and its tangent exit.
+ * weights (:289).  Follows the reference's bisection over the cut theta and its tangent exit.  p == 1 takes the
+ * weighted form of the level-median formula (emd1D_circle, :210-247); slice_theta then holds the median level.
  *   wu (n) or (pairs, n), wv (m) or (pairs, m): non-negative weights summing to 1, NULL = uniform;
  *   w*_pair_stride = 0 when one weight vector is shared by all pairs (the reference's usage), else n / m.
  *   slice_theta (pairs*slices) fp32 out, may be NULL : the cut the solve ended on.

@@ -195,7 +195,7 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
   if (!xs || !xt || !dirs || !slice_cost) return (int)hipErrorInvalidValue;
   if ((coef_s == nullptr) != (coef_t == nullptr)) return (int)hipErrorInvalidValue;
   if (pairs < 0 || slices < 0 || n < 1 || m < 1 || n > 4096 || m > 4096) return (int)hipErrorInvalidValue;
-  if (!(p > 1.f)) return (int)hipErrorInvalidValue;                // p == 1 is the level-median kernel
+  if (!(p >= 1.f)) return (int)hipErrorInvalidValue;               // p == 1: weighted level-median kernel
   if (u_pair_stride != 0 && u_pair_stride < (long)slices * 6) return (int)hipErrorInvalidValue;
   if ((wu_pair_stride != 0 && wu_pair_stride < n) || (wv_pair_stride != 0 && wv_pair_stride < m)) return (int)hipErrorInvalidValue;
   if (pairs == 0 || slices == 0) return 0;

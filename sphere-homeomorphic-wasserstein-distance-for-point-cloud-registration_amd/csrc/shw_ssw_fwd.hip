@@ -7,9 +7,11 @@ namespace shw {
 
 // register budget: the LDS footprint (EPT*256 B per wave) admits 20 waves per CU at EPT = 32, so
 // ask the allocator for 5 waves per SIMD there (<= 96 VGPRs); larger EPT take what they need.
-// The general-power variant (powf) is left at 4.
+// The general-power variant (powf) is left at 4.  At EPT = 64 the unconstrained allocator takes all 256
+// registers (1 wave per SIMD); asked for 3 waves it needs 144 with no spill, which is what 16 KB of LDS per
+// wave can use.
 constexpr int min_waves_per_simd(int ept, int pmode) {
-  return ept <= 16 ? (pmode == 2 ? 6 : 4) : (ept == 32 ? (pmode == 2 ? 5 : 3) : 1);
+  return ept <= 16 ? (pmode == 2 ? 6 : 4) : (ept == 32 ? (pmode == 2 ? 5 : 3) : (ept == 64 ? 3 : 1));
 }
 
 // FULL: n == m == 64*EPT (no padding atoms): mask-free projection and the fast shift evaluation.

@@ -38,6 +38,18 @@ struct Side {
   int count;
   __device__ __forceinline__ float v(int i) const { return val[lds_slot<EPT>(i)]; }
   __device__ __forceinline__ float c(int i) const { return cdf[lds_slot<EPT>(i)]; }
+  // number of atom VALUES < key (strict) or <= key (the p = 1 formula merges by value, not by CDF level)
+  __device__ __forceinline__ int values_below(float key, bool strict) const {
+    int lo = 0, hi = count;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const float x = v(mid);
+      const bool go = strict ? (x < key) : (x <= key);
+      lo = go ? mid + 1 : lo;
+      hi = go ? hi : mid;
+    }
+    return lo;
+  }
   // number of CDF entries < key (strict) or <= key  == torch.searchsorted(cdf, key, right = !strict)
   __device__ __forceinline__ int below(float key, bool strict) const {
     int lo = 0, hi = count;
@@ -198,29 +210,19 @@ __device__ __forceinline__ void sorted_cdf(float (&w)[EPT], int lane) {
   for (int r = 0; r < EPT; ++r) w[r] += offset;
 }
 
-template <int EPT, int PMODE, bool GRAD>
-__global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int ROW = EPT * kWave;
+// project, sort (with indices), gather weights and build the CDFs of both clouds of slice s; leaves the sorted
+// values / CDFs in LDS and the sorted->original index maps in registers
+template <int EPT>
+__device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int lane, float* s_val, float* s_cdf,
+                                              float* t_val, float* t_cdf, float* scratch, int (&sidx)[EPT],
+                                              int (&tidx)[EPT]) {
   const SswArgs& A = G.base;
-  const int lane = threadIdx.x & 63;
-  float* s_val = lds;
-  float* s_cdf = lds + ROW;
-  float* t_val = lds + 2 * ROW;
-  float* t_cdf = lds + 3 * ROW;
-  float* scratch = lds + 4 * ROW;                            // coordinates by original index; later gs
-  float* gt = lds + 5 * ROW;                                 // GRAD only
-
-  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
-  if (s >= A.pairs * A.slices) return;
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n, m = A.m;
   const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) U[i] = Ul[i];
-
-  int sidx[EPT], tidx[EPT];
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {                  // 0: target, 1: source
     const float* X = which == 0 ? A.xt + (long)b * m * 3 : A.xs + (long)b * n * 3;
@@ -243,11 +245,9 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     }
     sorted_cdf<EPT>(w, lane);
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int e = lane * EPT + r;                          // sorted position -> lds_slot(e) = r*64 + lane
+    for (int r = 0; r < EPT; ++r) {                          // sorted position lane*EPT + r -> slot r*64 + lane
       dval[r * kWave + lane] = val[r];
       dcdf[r * kWave + lane] = w[r];
-      (void)e;
     }
     if (which == 0) {
 #pragma unroll
@@ -258,6 +258,26 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int EPT, int PMODE, bool GRAD>
+__global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ROW = EPT * kWave;
+  const SswArgs& A = G.base;
+  const int lane = threadIdx.x & 63;
+  float* s_val = lds;
+  float* s_cdf = lds + ROW;
+  float* t_val = lds + 2 * ROW;
+  float* t_cdf = lds + 3 * ROW;
+  float* scratch = lds + 4 * ROW;                            // coordinates by original index; later gs
+  float* gt = lds + 5 * ROW;                                 // GRAD only
+
+  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
+  if (s >= A.pairs * A.slices) return;
+  const int n = A.n, m = A.m;
+  int sidx[EPT], tidx[EPT];
+  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
 
   Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
 
@@ -308,6 +328,128 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// p == 1 with weights: the reference's level-median formula (emd1D_circle, :210-247) on weighted atoms.
+// level = CDF difference after the atom in merged-by-value order (source before target on equal values),
+// gap = distance to the merged successor (the last atom: 1 - value; [0, first atom) is not integrated),
+// median = smallest level whose cumulated gap weight reaches 0.5 (the smallest level if the total never does),
+// cost = sum gap * |level - median|.  Levels are floats here, so the median is a float bisection followed by a
+// snap to the smallest level above the bracket.  Coefficients (GRAD): |level_before - med| - |level - med|,
+// the first merged atom -|level - med|.
+// ---------------------------------------------------------------------------------------------
+template <int EPT, bool GRAD>
+__global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ROW = EPT * kWave;
+  const SswArgs& A = G.base;
+  const int lane = threadIdx.x & 63;
+  float* s_val = lds;
+  float* s_cdf = lds + ROW;
+  float* t_val = lds + 2 * ROW;
+  float* t_cdf = lds + 3 * ROW;
+  float* scratch = lds + 4 * ROW;
+  float* lev_s = lds + 4 * ROW;                              // reuses scratch once the sorts are done
+  float* gap_s = lds + 5 * ROW;
+  float* lev_t = lds + 6 * ROW;
+  float* gap_t = lds + 7 * ROW;
+
+  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
+  if (s >= A.pairs * A.slices) return;
+  const int n = A.n, m = A.m;
+  int sidx[EPT], tidx[EPT];
+  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
+  Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
+
+  float lo_lev = __builtin_inff(), hi_lev = -__builtin_inff(), total = 0.f;
+#pragma nounroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    if (e < n) {                                             // source atom e
+      const float val = S.v(e);
+      const int lb = T.values_below(val, true);
+      const float lev = S.c(e) - (lb > 0 ? T.c(lb - 1) : 0.f);
+      const float nxt = fminf(e + 1 < n ? S.v(e + 1) : __builtin_inff(), lb < m ? T.v(lb) : __builtin_inff());
+      const float gap = (nxt == __builtin_inff() ? 1.f : nxt) - val;
+      lev_s[r * kWave + lane] = lev;
+      gap_s[r * kWave + lane] = gap;
+      lo_lev = fminf(lo_lev, lev); hi_lev = fmaxf(hi_lev, lev); total += gap;
+    }
+    if (e < m) {                                             // target atom e
+      const float val = T.v(e);
+      const int ub = S.values_below(val, false);
+      const float lev = (ub > 0 ? S.c(ub - 1) : 0.f) - T.c(e);
+      const float nxt = fminf(e + 1 < m ? T.v(e + 1) : __builtin_inff(), ub < n ? S.v(ub) : __builtin_inff());
+      const float gap = (nxt == __builtin_inff() ? 1.f : nxt) - val;
+      lev_t[r * kWave + lane] = lev;
+      gap_t[r * kWave + lane] = gap;
+      lo_lev = fminf(lo_lev, lev); hi_lev = fmaxf(hi_lev, lev); total += gap;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  lo_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(-wave_max(-lo_lev, lane))));
+  hi_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(wave_max(hi_lev, lane))));
+  total = wave_sum_uniform(total, lane);
+
+  auto weight_below = [&](float t) -> float {               // sum of gaps of atoms with level <= t
+    float w = 0.f;
+#pragma nounroll
+    for (int r = 0; r < EPT; ++r) {
+      const int e = lane * EPT + r;
+      if (e < n && lev_s[r * kWave + lane] <= t) w += gap_s[r * kWave + lane];
+      if (e < m && lev_t[r * kWave + lane] <= t) w += gap_t[r * kWave + lane];
+    }
+    return wave_sum_uniform(w, lane);
+  };
+  float med = lo_lev;
+  if (total >= 0.5f) {
+    float lo = lo_lev - 1.f, hi = hi_lev;                    // W(lo) = 0 < 0.5 <= W(hi) = total
+    for (int it = 0; it < 48 && lo < hi; ++it) {
+      const float mid = lo + (hi - lo) * 0.5f;
+      if (!(mid > lo && mid < hi)) break;                    // bracket exhausted at fp32 resolution
+      if (weight_below(mid) >= 0.5f) hi = mid; else lo = mid;
+    }
+    float best = __builtin_inff();                           // smallest level above the bracket's lower end
+#pragma nounroll
+    for (int r = 0; r < EPT; ++r) {
+      const int e = lane * EPT + r;
+      if (e < n) { const float l = lev_s[r * kWave + lane]; best = (l > lo) ? fminf(best, l) : best; }
+      if (e < m) { const float l = lev_t[r * kWave + lane]; best = (l > lo) ? fminf(best, l) : best; }
+    }
+    med = as_f(__builtin_amdgcn_readfirstlane(as_i(-wave_max(-best, lane))));
+  }
+
+  float acc = 0.f;
+  float* cs = GRAD ? A.coef_s + (long)s * n : nullptr;
+  float* ct = GRAD ? A.coef_t + (long)s * m : nullptr;
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    if (e < n) {
+      const float lev = lev_s[r * kWave + lane], here = fabsf(lev - med);
+      acc += gap_s[r * kWave + lane] * here;
+      if constexpr (GRAD) {
+        const float own = S.c(e) - (e > 0 ? S.c(e - 1) : 0.f);
+        const bool first = (e == 0) && (T.values_below(S.v(0), true) == 0);
+        cs[sidx[r]] = (first ? 0.f : fabsf(lev - own - med)) - here;
+      }
+    }
+    if (e < m) {
+      const float lev = lev_t[r * kWave + lane], here = fabsf(lev - med);
+      acc += gap_t[r * kWave + lane] * here;
+      if constexpr (GRAD) {
+        const float own = T.c(e) - (e > 0 ? T.c(e - 1) : 0.f);
+        const bool first = (e == 0) && (S.values_below(T.v(0), false) == 0);
+        ct[tidx[r]] = (first ? 0.f : fabsf(lev + own - med)) - here;
+      }
+    }
+  }
+  const float cost = wave_sum_uniform(acc, lane);
+  if (lane == 0) {
+    A.slice_cost[s] = cost;
+    if (G.slice_theta) G.slice_theta[s] = med;
+  }
+}
+
 template <int EPT>
 static int launch_general(GeneralArgs& G, hipStream_t stream) {
   SswArgs& A = G.base;
@@ -315,8 +457,15 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
   const bool grad = A.coef_s != nullptr;
-  const size_t lds = (size_t)(grad ? 6 : 5) * EPT * kWave * sizeof(float);
   const dim3 grid((unsigned)total), block(64);
+  if (A.p == 1.f) {
+    const size_t lds1 = (size_t)8 * EPT * kWave * sizeof(float);
+    if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (grad) hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, true>), grid, block, lds1, stream, G);
+    else hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, false>), grid, block, lds1, stream, G);
+    return (int)hipGetLastError();
+  }
+  const size_t lds = (size_t)(grad ? 6 : 5) * EPT * kWave * sizeof(float);
   if (A.p_int == 2) {
     if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, 2, true>), grid, block, lds, stream, G);
     else hipLaunchKernelGGL((ssw_general_kernel<EPT, 2, false>), grid, block, lds, stream, G);

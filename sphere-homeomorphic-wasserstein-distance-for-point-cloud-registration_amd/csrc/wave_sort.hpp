@@ -218,6 +218,16 @@ __device__ __forceinline__ float wave_sum(float v, int lane) {
   return v;
 }
 
+__device__ __forceinline__ float wave_max(float v, int lane) {
+  v = fmaxf(v, lane_xor<1>(v, lane));
+  v = fmaxf(v, lane_xor<2>(v, lane));
+  v = fmaxf(v, lane_xor<4>(v, lane));
+  v = fmaxf(v, lane_xor<8>(v, lane));
+  v = fmaxf(v, lane_xor<16>(v, lane));
+  v = fmaxf(v, lane_xor<32>(v, lane));
+  return v;
+}
+
 // same, but the result is handed back through an SGPR so that the compiler's divergence analysis
 // knows it is wave-uniform (branches on it become scalar branches, values derived from it stay in
 // SGPRs instead of being recomputed per lane)

@@ -77,7 +77,8 @@ class _PairLosses(torch.autograd.Function):
         pair_loss = torch.empty(B, dtype=torch.float32, device=dev)
         need_grad = Xs.requires_grad or Xt.requires_grad
         stream = _stream_ptr(dev)
-        general = float(p) != 1.0 and (n != m or wu is not None or wv is not None)
+        weighted = wu is not None or wv is not None
+        general = weighted or (float(p) != 1.0 and n != m)      # p == 1 with uniform weights: level-median kernel
         with torch.cuda.device(dev):
             if general:
                 # n != m and / or weights: the reference's bisection over the cut, followed step for step
@@ -150,7 +151,7 @@ def _check_weights(name, w, count, B, dev):
 
 def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weights=None):
     """Core op: batched clouds (B,n,3), (B,m,3); directions (B,L,3,2) or shared (L,3,2); optional weights
-    (n,) / (B,n) and (m,) / (B,m) (p != 1 only).
+    (n,) / (B,n) and (m,) / (B,m).
     Returns (B,) per-pair losses = mean over slices of W_p^p on the slice circle
     [optionally also the (B,L) per-slice costs and optimal shifts]."""
     _check_cloud("Xs", Xs)
@@ -167,9 +168,6 @@ def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weig
         raise ValueError("need at least one slice and one point per cloud")
     wu = _check_weights("u_weights", u_weights, Xs.shape[1], Xs.shape[0], Xs.device)
     wv = _check_weights("v_weights", v_weights, Xt.shape[1], Xs.shape[0], Xs.device)
-    if (wu is not None or wv is not None) and float(p) == 1.0:
-        raise NotImplementedError("weights with p == 1 (the level-median kernel assumes uniform weights) are not "
-                                  "implemented in the HIP path; refusing to fall back to a CPU path")
     pair, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared, wu, wv)
     if return_slices:
         return pair, cost, shift
