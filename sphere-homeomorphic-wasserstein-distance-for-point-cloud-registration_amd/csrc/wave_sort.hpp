@@ -32,6 +32,9 @@ __device__ __forceinline__ float dpp_mov(float x) {
 }
 
 // value of `x` held by lane (lane ^ MASK); every lane of the wave must be active.
+#ifndef SHW_XLANE_BATCH
+#define SHW_XLANE_BATCH 8
+#endif
 #ifndef SHW_XLANE_DPP
 #define SHW_XLANE_DPP 0   // 0: every cross-lane move on the LDS crossbar (ds_swizzle / ds_bpermute);
 #endif                    // 1: DPP v_mov for the masks DPP can express.  Measured on MI355X: the kernels
@@ -139,8 +142,17 @@ template <class P, int EPT, int M>
 __device__ __forceinline__ void xlane_stages(typename P::type (&x)[EPT], int lane) {
   if constexpr (M >= 1) {
     const typename P::type bnd = P::bound((lane & M) != 0);
+    // batches of SHW_XLANE_BATCH moves in flight before their compare-exchanges: a wave then stalls once per
+    // batch for the LDS-crossbar latency instead of once per handful of elements (hipcc on its own keeps 5)
+    constexpr int CH = EPT < SHW_XLANE_BATCH ? EPT : SHW_XLANE_BATCH;
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) x[r] = P::pick(x[r], lane_xor<M>(x[r], lane), bnd);
+    for (int r0 = 0; r0 < EPT; r0 += CH) {
+      typename P::type part[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) part[j] = lane_xor<M>(x[r0 + j], lane);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) x[r0 + j] = P::pick(x[r0 + j], part[j], bnd);
+    }
     xlane_stages<P, EPT, M / 2>(x, lane);
   }
 }
