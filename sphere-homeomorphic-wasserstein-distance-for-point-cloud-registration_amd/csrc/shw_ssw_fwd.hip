@@ -62,6 +62,153 @@ __global__ __launch_bounds__(WAVES * 64, min_waves_per_simd(EPT, PMODE)) void ss
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-wave form for 2048 < n <= 8192: W = 2 or 4 wavefronts of one workgroup share a slice.  Each wave
+// sorts its chunk of 2048 keys in registers exactly as above; the chunks are then merged by the remaining
+// levels of the same bitonic network, whose first stages pair elements of DIFFERENT waves: those go through
+// one LDS exchange each (write 32 registers, barrier, read the partner wave's slot, barrier), and because the
+// "lower / upper" role of such a stage is the same for a whole wave they are plain v_min / v_max.  The stages
+// below the wave level are the single-wave code (xlane_stages, lane_stages).  The source is sorted first and
+// stays in registers while the target is sorted; the exchange buffer then becomes the sorted target, so LDS
+// stays at 8 KB per wave and registers at the 2048-point budget (the one-wave kernels for these sizes need 64
+// and 128 keys per lane: 1 wave per SIMD, and spills at 8192).  The shift solve runs in every wave on its own
+// 2048 source atoms; the three partial sums are added across waves in wave order through LDS, so all waves
+// take identical decisions.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void cross_wave_exchange(float (&key)[32], float* buf, int wave, int lane, int partner,
+                                                    bool mirror, bool upper) {
+  constexpr int NCOL = 64 * W;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) buf[r * NCOL + wave * 64 + lane] = key[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const float p = mirror ? buf[(31 - r) * NCOL + partner * 64 + (63 - lane)] : buf[r * NCOL + partner * 64 + lane];
+    key[r] = upper ? __builtin_fmaxf(key[r], p) : __builtin_fminf(key[r], p);
+  }
+  __syncthreads();
+}
+
+template <int W>
+__device__ __forceinline__ void merge_across_waves(float (&key)[32], float* buf, int wave, int lane) {
+#pragma unroll
+  for (int c = 1; (1 << c) <= W; ++c) {                       // merge blocks of 2^c waves
+    cross_wave_exchange<W>(key, buf, wave, lane, wave ^ ((1 << c) - 1), true, (wave & (1 << (c - 1))) != 0);
+#pragma unroll
+    for (int t = c - 2; t >= 0; --t)
+      cross_wave_exchange<W>(key, buf, wave, lane, wave ^ (1 << t), false, (wave & (1 << t)) != 0);
+    xlane_stages<F32Keys, 32, 32>(key, lane);
+    lane_stages<F32Keys, 32, 16>(key);
+  }
+}
+
+template <int W, int PMODE, bool FULL>
+__global__ __launch_bounds__(W * 64, 4) void ssw_forward_mw_kernel(SswArgs A) {
+  constexpr int EPT = 32, NCOL = 64 * W, CHUNK = EPT * kWave;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* buf = lds;                                            // [EPT][NCOL]: exchange buffer, then sorted target
+  float* red = lds + EPT * NCOL;                               // [W][4] partial sums
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);  // one workgroup per (pair, slice)
+  const int b = s / A.slices, l = s - b * A.slices;
+  const int n = A.n;
+  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
+  float U[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+
+  float u[EPT], key[EPT];
+  float part_u = 0.f, part_v = 0.f;
+  const int first = wave * CHUNK;                              // first point of this wave's chunk
+  const int chunk_live = max(0, min(CHUNK, n - first));
+#pragma nounroll
+  for (int which = 0; which < 2; ++which) {                    // 0: source -> registers, 1: target -> LDS
+    const float* X = (which == 0 ? A.xs : A.xt) + (long)b * n * 3;
+    const int base = min(first, n - 1);                        // keep the addresses of an empty chunk in bounds
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const float part = load_coords<EPT, FULL>(X + (long)base * 3, n - base, ln, U, key, chunk_live);
+    wave_sort<EPT>(key, ln);
+    merge_across_waves<W>(key, buf, wave, ln);
+    if (which == 0) {
+      part_u = wave_sum_uniform(part, lane);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) u[r] = key[r];
+    } else {
+      part_v = wave_sum_uniform(part, lane);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) buf[r * NCOL + wave * 64 + lane] = key[r];
+    }
+  }
+  if (lane == 0) { red[wave * 4] = part_u; red[wave * 4 + 1] = part_v; }
+  __syncthreads();
+  float sum_u = 0.f, sum_v = 0.f;
+#pragma unroll
+  for (int w = 0; w < W; ++w) { sum_u += red[w * 4]; sum_v += red[w * 4 + 1]; }
+  __syncthreads();
+
+  // minimise the convex sequence c(k), |k| <= n: solve_shift with the partial sums added across waves
+  int lo = -n, hi = n;
+  float guess = rintf(sum_u - sum_v);
+  guess = fminf(fmaxf(guess, (float)lo), (float)hi);
+  int k = __builtin_amdgcn_readfirstlane((int)guess);
+  bool lo_tight = false, hi_tight = false;
+  int step = 1;
+  float cm = 0.f, c0 = 0.f, cp = 0.f;
+  const int glane = wave * 64 + lane;
+  for (int it = 0; it < 64; ++it) {
+    int gl = glane;
+    asm volatile("" : "+v"(gl));
+    float pm, p0, pp;
+    if constexpr (FULL) shift_costs3_full<EPT, PMODE, NCOL>(u, buf, gl, k, A.p, A.p_int, pm, p0, pp);
+    else shift_costs3<EPT, PMODE, NCOL>(u, buf, gl, n, k, A.p, A.p_int, pm, p0, pp);
+    if (lane == 0) { red[wave * 4] = pm; red[wave * 4 + 1] = p0; red[wave * 4 + 2] = pp; }
+    __syncthreads();
+    cm = c0 = cp = 0.f;
+#pragma unroll
+    for (int w = 0; w < W; ++w) { cm += red[w * 4]; c0 += red[w * 4 + 1]; cp += red[w * 4 + 2]; }
+    cm = as_f(__builtin_amdgcn_readfirstlane(as_i(cm)));
+    c0 = as_f(__builtin_amdgcn_readfirstlane(as_i(c0)));
+    cp = as_f(__builtin_amdgcn_readfirstlane(as_i(cp)));
+    __syncthreads();
+    const bool right = (cp < c0) && (k < hi);
+    const bool left = !right && (cm < c0) && (k > lo);
+    if (!right && !left) break;
+    if (right) {
+      lo = k + 1; lo_tight = true;
+      if (hi_tight) { k = lo + ((hi - lo) >> 1); } else { k = min(k + step, hi); step <<= 1; }
+    } else {
+      hi = k - 1; hi_tight = true;
+      if (lo_tight) { k = lo + ((hi - lo) >> 1); } else { k = max(k - step, lo); step <<= 1; }
+    }
+    k = __builtin_amdgcn_readfirstlane(k);
+  }
+  if (threadIdx.x == 0) {
+    A.slice_cost[s] = c0 / (float)n;
+    if (A.slice_shift) A.slice_shift[s] = k;
+  }
+}
+
+template <int W>
+static int launch_forward_mw(SswArgs& A, hipStream_t stream) {
+  const long total = (long)A.pairs * A.slices;
+  if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  A.num_groups = (int)total;
+  const size_t lds = (size_t)(32 * 64 * W + 4 * W) * sizeof(float);
+  const bool full = (A.n == 2048 * W) && (A.m == 2048 * W);
+  const dim3 grid((unsigned)total), block(W * 64);
+  if (A.p_int == 2) {
+    if (full) hipLaunchKernelGGL((ssw_forward_mw_kernel<W, 2, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_mw_kernel<W, 2, false>), grid, block, lds, stream, A);
+  } else {
+    if (full) hipLaunchKernelGGL((ssw_forward_mw_kernel<W, 0, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_mw_kernel<W, 0, false>), grid, block, lds, stream, A);
+  }
+  return (int)hipGetLastError();
+}
+
 template <int EPT, int WAVES>
 static int launch_forward(SswArgs& A, hipStream_t stream) {
   const long total = (long)A.pairs * A.slices;
@@ -98,8 +245,8 @@ int dispatch_forward(SswArgs& A, hipStream_t stream) {
     case 8: return launch_forward<8, 4>(A, stream);
     case 16: return launch_forward<16, 4>(A, stream);
     case 32: return launch_forward<32, 4>(A, stream);
-    case 64: return launch_forward<64, 2>(A, stream);
-    case 128: return launch_forward<128, 1>(A, stream);
+    case 64: return launch_forward_mw<2>(A, stream);            // 2049..4096 points: two waves per slice
+    case 128: return launch_forward_mw<4>(A, stream);           // 4097..8192 points: four waves per slice
 #endif
     default: return (int)hipErrorInvalidValue;
   }

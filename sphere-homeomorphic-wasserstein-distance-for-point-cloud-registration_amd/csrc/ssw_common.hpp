@@ -118,40 +118,44 @@ __device__ __forceinline__ float dpow_abs(float d, float p, int p_int) {
 
 // sorted target in LDS: sorted position q lives at [(q % EPT) * 64 + q / EPT]  (= register r of
 // lane q/EPT, written with one conflict-free ds_write per register).
-template <int EPT>
+// NCOL = number of columns = lanes that hold the sorted array: 64 for one wave, 64*W when W waves of a
+// workgroup sort one slice together (shw_ssw_fwd.hip, multi-wave kernel).
+template <int EPT, int NCOL = 64>
 __device__ __forceinline__ int lds_slot(int q) {
   constexpr int LOG = __builtin_ctz(EPT);
-  return ((q & (EPT - 1)) << 6) + (q >> LOG);
+  return (q & (EPT - 1)) * NCOL + (q >> LOG);
 }
 
 // v_ext(q) for q in [-2n, 3n): branch-free wrap onto [0, n) with the turn offset (two turns each
 // way: the shift k ranges over [-n, n] and its neighbours k-1, k+1 are evaluated alongside)
-template <int EPT>
+template <int EPT, int NCOL = 64>
 __device__ __forceinline__ float target_unrolled(const float* vbuf, int q, int n) {
   const int t1 = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
   q -= t1 * n;
   const int t2 = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
   q -= t2 * n;
-  return vbuf[lds_slot<EPT>(q)] + (float)(t1 + t2);
+  return vbuf[lds_slot<EPT, NCOL>(q)] + (float)(t1 + t2);
 }
 
 // c(k-1), c(k), c(k+1) (sums, not yet divided by n), valid in every lane.
 // Lane owns sorted positions e0 .. e0+EPT-1 and needs v_ext(e0+k-1 .. e0+k+EPT): a sliding window,
 // fetched 8 positions at a time to bound the registers in flight.
-template <int EPT, int PMODE>
+// `lane` is the index of the lane among the NCOL lanes that hold the slice (wave * 64 + lane in the multi-wave
+// kernel, whose waves then add their partial sums).
+template <int EPT, int PMODE, int NCOL = 64>
 __device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float* vbuf, int lane, int n,
                                              int k, float p, int p_int, float& cm, float& c0, float& cp) {
   float sm = 0.f, s0 = 0.f, sp = 0.f;
   const int e0 = lane * EPT;
   const int last = n - 1;
-  float prev = target_unrolled<EPT>(vbuf, min(e0, last) + k - 1, n);
-  float cur = target_unrolled<EPT>(vbuf, min(e0, last) + k, n);
+  float prev = target_unrolled<EPT, NCOL>(vbuf, min(e0, last) + k - 1, n);
+  float cur = target_unrolled<EPT, NCOL>(vbuf, min(e0, last) + k, n);
   constexpr int CH = EPT < 8 ? EPT : 8;
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
     float nxt[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) nxt[j] = target_unrolled<EPT>(vbuf, min(e0 + r0 + j, last) + k + 1, n);
+    for (int j = 0; j < CH; ++j) nxt[j] = target_unrolled<EPT, NCOL>(vbuf, min(e0 + r0 + j, last) + k + 1, n);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const bool live = (e0 + r0 + j) < n;
@@ -166,9 +170,9 @@ __device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float*
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  cm = wave_sum_uniform(sm, lane);
-  c0 = wave_sum_uniform(s0, lane);
-  cp = wave_sum_uniform(sp, lane);
+  cm = wave_sum_uniform(sm, lane & 63);
+  c0 = wave_sum_uniform(s0, lane & 63);
+  cp = wave_sum_uniform(sp, lane & 63);
 }
 
 // Fast form of shift_costs3 for n == 64*EPT exactly (every register slot is a real atom, n a power of
@@ -176,7 +180,7 @@ __device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float*
 // position (l + kh + c)*EPT + row with  row = (kl + j) mod EPT  and carry  c = (kl + j) div EPT in
 // {0,1,2}: row and c are WAVE-UNIFORM, so each fetch is  ds_read(addr_c + row*256) + turn_c  with the
 // three per-lane (address, turn) pairs prepared once per evaluation -- 4 VALU per fetch instead of ~15.
-template <int EPT, int PMODE>
+template <int EPT, int PMODE, int NCOL = 64>
 __device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const float* vbuf, int lane, int k,
                                                   float p, int p_int, float& cm, float& c0, float& cp) {
   constexpr int LOG = __builtin_ctz(EPT);
@@ -188,8 +192,8 @@ __device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const f
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int col = lane + kh + c;                              // unwrapped lane index of the atom
-    addr[c] = (col & 63) << 2;                                  // byte offset inside an LDS row
-    turn[c] = (float)(col >> 6);                                // whole turns around the circle
+    addr[c] = (col & (NCOL - 1)) << 2;                          // byte offset inside an LDS row
+    turn[c] = (float)(col >> __builtin_ctz(NCOL));              // whole turns around the circle
   }
   const char* rows = reinterpret_cast<const char*>(vbuf);
   auto fetch = [&](int j) -> float {                            // j compile-time after unrolling
@@ -198,7 +202,7 @@ __device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const f
     const bool carry = (j < EPT) ? (rj >= EPT) : (rj >= 2 * EPT);
     const int a = (j < EPT) ? (carry ? addr[1] : addr[0]) : (carry ? addr[2] : addr[1]);
     const float t = (j < EPT) ? (carry ? turn[1] : turn[0]) : (carry ? turn[2] : turn[1]);
-    return *reinterpret_cast<const float*>(rows + a + (row << 8)) + t;
+    return *reinterpret_cast<const float*>(rows + a + row * (NCOL * 4)) + t;
   };
   float sm = 0.f, s0 = 0.f, sp = 0.f;
   float prev = fetch(0), cur = fetch(1);
@@ -218,9 +222,9 @@ __device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const f
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  cm = wave_sum_uniform(sm, lane);
-  c0 = wave_sum_uniform(s0, lane);
-  cp = wave_sum_uniform(sp, lane);
+  cm = wave_sum_uniform(sm, lane & 63);
+  c0 = wave_sum_uniform(s0, lane & 63);
+  cp = wave_sum_uniform(sp, lane & 63);
 }
 
 // Minimise the convex sequence c(k), |k| <= n (theta in [-1, 1], the reference's bracket :174-177).
@@ -266,7 +270,10 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
 // records).  Padding keys are +inf so that they sort behind every real coordinate.
 template <int EPT, bool FULL = false>
 __device__ __forceinline__ float load_coords(const float* __restrict__ X, int count, int lane,
-                                             const float (&U)[6], float (&key)[EPT]) {
+                                             const float (&U)[6], float (&key)[EPT], int live_count = -1) {
+  // `count` bounds the addresses (clamp), `live_count` (default: count) says how many of the 64*EPT slots are
+  // real atoms; they differ only for the trailing chunks of the multi-wave kernel
+  if (live_count < 0) live_count = count;
   float acc = 0.f;
   constexpr int CH = EPT < 8 ? EPT : 8;            // 8 points (24 loads) in flight per lane
 #pragma unroll
@@ -286,7 +293,7 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
       const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
       const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], fmaf(px[j], U[1], 0.f)));
       const float c = circle_coord(a, b);
-      const bool live = FULL || (i < count);
+      const bool live = FULL || (i < live_count);
       acc += live ? c : 0.f;
       key[r0 + j] = live ? c : __builtin_inff();
     }
