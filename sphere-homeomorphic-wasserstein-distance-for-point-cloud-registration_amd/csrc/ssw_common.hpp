@@ -393,14 +393,17 @@ __device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X
   bool collide = false;                                  // equal quantised coordinate on adjacent atoms?
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
-    const bool pad = pk[r] == 0xffffffffu;
-    idx[r] = pad ? (int)PK::IDX_MASK : (int)(pk[r] & PK::IDX_MASK);
+    // A pad is recognised by its index field (all ones, >= count whenever pads exist), NOT by the key value:
+    // the real atom with index 64*EPT-1 and a coordinate in the top quantisation cell packs to the same word
+    // 0xffffffff when the row is full.
+    idx[r] = (int)(pk[r] & PK::IDX_MASK);
+    const bool pad = idx[r] >= count;
     val[r] = pad ? __builtin_inff() : orig[idx[r]];
     if (r > 0) collide |= ((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0 && !pad;
   }
   {
     const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)pk[0]);
-    collide |= (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) && (pk[EPT - 1] != 0xffffffffu);
+    collide |= (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) && (idx[EPT - 1] < count);
   }
   if (__builtin_amdgcn_readfirstlane((int)(__ballot(collide) != 0ull)) != 0) exact_order_fixup<EPT>(val, idx, lane);
   __builtin_amdgcn_wave_barrier();

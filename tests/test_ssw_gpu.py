@@ -992,3 +992,38 @@ def test_adversarial_clouds_against_float64_oracle(shw, kind, n):
         #  segment and the median pick; those three families are near-tie dominated by construction)
         assert np.all(np.abs(g1 - ref1) <= 1e-4 * ref1 + 1e-7), (g1, ref1)
     assert np.all(np.isfinite(g1))
+
+
+@pytest.mark.parametrize("n", [64, 256, 1024, 2048, 4096])
+@pytest.mark.parametrize("which", ["source", "target", "both"])
+def test_last_point_in_top_quantisation_cell_of_a_full_row(shw, n, which):
+    """Regression: in the training kernel's packed sort the atom with the LAST original index and a coordinate
+    within 2^-QBITS of 1 packs to the all-ones word, which used to be taken for a padding slot (-> +inf cost,
+    NaN gradients; seen once in ~1e5 slices of a training run).  Costs with gradients must equal the
+    forward-only kernel's, which sorts plain float keys."""
+    g = torch.Generator().manual_seed(n)
+    x, y = unit_cloud(g, n), unit_cloud(g, n)
+    U = directions(g, 8)
+    edge = 0.5 * U[3, :, 0] - 1e-7 * U[3, :, 1]          # coordinate 1 - 3e-8 on slice 3
+    if which in ("source", "both"):
+        x[n - 1] = edge
+    if which in ("target", "both"):
+        y[n - 1] = edge * 1.5
+    _, want, want_k = shw.ssw_pair_losses(x.cuda()[None], y.cuda()[None], U.cuda(), p=2, return_slices=True)
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, got, got_k = shw.ssw_pair_losses(xs[None], ys[None], U.cuda(), p=2, return_slices=True)
+    pair.sum().backward()
+    assert torch.isfinite(got).all() and torch.isfinite(xs.grad).all() and torch.isfinite(ys.grad).all()
+    assert torch.equal(got_k, want_k)
+    assert torch.allclose(got, want, rtol=1e-6, atol=0)
+    if n <= 1024:
+        from oracle import exact_shift
+        gx, gy = exact_shift.ssw_pair_grad(x.numpy(), y.numpy(), U.numpy(), 2)
+        grad_close(xs.grad.cpu().numpy(), gx)
+        grad_close(ys.grad.cpu().numpy(), gy)
+    # weighted (general) path sorts through the same packed helper
+    w = torch.full((n,), 1.0 / n, device="cuda")
+    if n <= 2048:
+        _, got_w, _ = shw.ssw_pair_losses(x.cuda()[None], y.cuda()[None], U.cuda(), p=2, return_slices=True, u_weights=w, v_weights=w)
+        assert torch.isfinite(got_w).all()
+        assert torch.allclose(got_w, want, rtol=2e-4, atol=1e-7)
