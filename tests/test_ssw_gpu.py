@@ -1027,3 +1027,17 @@ def test_last_point_in_top_quantisation_cell_of_a_full_row(shw, n, which):
         _, got_w, _ = shw.ssw_pair_losses(x.cuda()[None], y.cuda()[None], U.cuda(), p=2, return_slices=True, u_weights=w, v_weights=w)
         assert torch.isfinite(got_w).all()
         assert torch.allclose(got_w, want, rtol=2e-4, atol=1e-7)
+
+
+def test_short_soak_of_every_kernel_family(shw):
+    """Ten seconds of tools/soak.py: random batches of several shapes and families through the forward, training,
+    p = 1, general, Chamfer and Euclidean kernels with NaN-poisoned allocator memory; paths that must agree are
+    compared with each other (~5e6 slices per path).  The four-minute form of the same run is how the packed-sort
+    pad collision was characterised."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py")
+    spec = importlib.util.spec_from_file_location("shw_soak", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(budget=10.0) == 0

@@ -1,0 +1,111 @@
+"""Soak check (development aid, GPU): many random batches through every kernel family, comparing code paths
+that must agree with each other, with the allocator's free memory NaN-poisoned between calls so that any read
+of an unwritten scratch word shows.
+
+  forward-only vs training kernel : per-slice costs equal to 3e-6, shifts equal (but for exact ties)
+  p = 1                           : finite, >= 0
+  general solver (uniform weights): equals the equal-size path to 2e-4
+  backward                        : finite gradients
+  Chamfer / Euclidean SW          : finite
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import shw_amd as shw  # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def poison():
+    blocks = [torch.full((s,), float("nan"), device=dev) for s in (1 << 26, 1 << 24, 1 << 22, 1 << 20, 1 << 16, 1 << 12, 256, 8) for _ in range(3)]
+    del blocks
+
+
+def clouds(kind, B, n, m, gen):
+    x = torch.randn(B, n, 3, generator=gen)
+    y = torch.randn(B, m, 3, generator=gen)
+    if kind == "sphere":
+        x, y = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(y, dim=-1)
+    elif kind == "registration" and n == m:       # y = slightly moved / noisy copy of x: tiny costs, shifts near 0
+        y = x + 0.01 * y
+    elif kind == "centred" and n > 1:             # (a single centred point IS the origin: 0/0 gradient, also in the reference)
+        x = x - x.mean(1, keepdim=True)
+        y = y - y.mean(1, keepdim=True)
+    elif kind == "grid":                          # coordinates on a coarse lattice: masses of exact ties
+        x, y = torch.round(x * 4) / 4 + 0.01, torch.round(y * 4) / 4 + 0.01
+    return x.to(dev), y.to(dev)
+
+
+def main(budget=None):
+    if budget is None:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    gen = torch.Generator().manual_seed(2025)
+    t_end = time.time() + budget
+    slices_done, trips, bad = 0, 0, 0
+    sizes = [(64, 64), (256, 256), (1000, 1000), (1024, 1024), (2048, 2048), (2000, 2000), (4096, 4096), (100, 100), (1, 1), (63, 63), (65, 65)]
+    kinds = ["sphere", "registration", "centred", "grid", "gauss"]
+    while time.time() < t_end:
+        n, m = sizes[trips % len(sizes)]
+        kind = kinds[(trips // len(sizes)) % len(kinds)]
+        B = max(1, min(64, 65536 // n))
+        L = 256
+        x, y = clouds(kind, B, n, m, gen)
+        U = shw.draw_directions(L, dev, batch=B, d=3)
+        poison()
+        _, c_f, k_f = shw.ssw_pair_losses(x, y, U, 2, return_slices=True)
+        poison()
+        xs, ys = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        pair, c_g, k_g = shw.ssw_pair_losses(xs, ys, U, 2, return_slices=True)
+        poison()
+        pair.sum().backward()
+        poison()
+        _, c_1, _ = shw.ssw_pair_losses(x, y, U, 1, return_slices=True)
+        poison()
+        pair3, c_3, _ = shw.ssw_pair_losses(xs, ys, U, 3, return_slices=True)
+        problems = []
+        if not torch.allclose(c_f, c_g, rtol=3e-6, atol=1e-12):          # summation orders differ by an ulp or two
+            problems.append(f"forward vs training cost differ: max rel {float(((c_f - c_g).abs() / (c_f + 1e-12)).max())}")
+        if float((k_f != k_g).float().mean()) > 0.01:                    # exact cost ties may pick either shift
+            problems.append("forward vs training shifts differ on > 1% of the slices")
+        for name, t in (("cost", c_f), ("p1", c_1), ("p3", c_3), ("gx", xs.grad), ("gy", ys.grad)):
+            if not bool(torch.isfinite(t).all()):
+                problems.append(f"non-finite {name}: {int((~torch.isfinite(t)).sum())}")
+        if bool((c_f < 0).any()) or bool((c_1 < 0).any()):
+            problems.append("negative cost")
+        if n <= 2048 and trips % 3 == 0:
+            w = torch.full((n,), 1.0 / n, device=dev)
+            poison()
+            _, c_w, _ = shw.ssw_pair_losses(x, y, U, 2, return_slices=True, u_weights=w, v_weights=w)
+            if not torch.allclose(c_w, c_f, rtol=5e-4, atol=1e-7):
+                problems.append(f"general vs equal-size: max rel {float(((c_w - c_f).abs() / (c_f + 1e-7)).max())}")
+        if trips % 5 == 0:
+            poison()
+            cd = shw.chamfer_distance(xs, ys)
+            cd0 = cd[0] if isinstance(cd, (tuple, list)) else cd
+            if not bool(torch.isfinite(cd0).all()):
+                problems.append("chamfer non-finite")
+            poison()
+            e = shw.sliced_wasserstein_distance(x[0], y[0], num_projection=64, p=2, device=dev)
+            if not bool(torch.isfinite(e).all()):
+                problems.append("esw non-finite")
+        if problems:
+            bad += 1
+            print("PROBLEM", kind, n, m, B, problems, flush=True)
+            os.makedirs("gpurun_out", exist_ok=True)
+            torch.save({"x": x.cpu(), "y": y.cpu(), "U": U.cpu(), "c_f": c_f.cpu(), "c_g": c_g.detach().cpu()}, f"gpurun_out/soak_bad{bad}.pt")
+            if bad >= 5:
+                break
+        slices_done += B * L
+        trips += 1
+        if trips % 50 == 0:
+            print(f"{trips} trips, {slices_done} slices per path, {bad} problems", flush=True)
+    print(f"done: {trips} trips, {slices_done} slices per path, {bad} problems")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
