@@ -46,7 +46,7 @@ def main(budget=None):
     gen = torch.Generator().manual_seed(2025)
     t_end = time.time() + budget
     slices_done, trips, bad = 0, 0, 0
-    sizes = [(64, 64), (256, 256), (1000, 1000), (1024, 1024), (2048, 2048), (2000, 2000), (4096, 4096), (100, 100), (1, 1), (63, 63), (65, 65)]
+    sizes = [(64, 64), (256, 256), (1000, 1000), (1024, 1024), (2048, 2048), (2000, 2000), (4096, 4096), (100, 100), (1, 1), (63, 63), (65, 65), (8192, 8192), (3000, 3000), (130, 130)]
     kinds = ["sphere", "registration", "centred", "grid", "gauss"]
     while time.time() < t_end:
         n, m = sizes[trips % len(sizes)]
@@ -82,16 +82,38 @@ def main(budget=None):
             _, c_w, _ = shw.ssw_pair_losses(x, y, U, 2, return_slices=True, u_weights=w, v_weights=w)
             if not torch.allclose(c_w, c_f, rtol=5e-4, atol=1e-7):
                 problems.append(f"general vs equal-size: max rel {float(((c_w - c_f).abs() / (c_f + 1e-7)).max())}")
+        if trips % 4 == 1 and 2 <= n <= 2048:
+            # unequal sizes + random weights: W(mu, nu) == W(nu, mu); finite gradients; weighted p = 1 finite
+            m2 = max(1, n - 1 - (trips % 7))
+            y2 = y[:, :m2].contiguous().requires_grad_(True)
+            wu = torch.rand(B, n, generator=gen).to(dev) + 0.05
+            wu = wu / wu.sum(1, keepdim=True)
+            wv = torch.rand(B, m2, generator=gen).to(dev) + 0.05
+            wv = wv / wv.sum(1, keepdim=True)
+            poison()
+            pair_a, c_a, _ = shw.ssw_pair_losses(xs, y2, U, 2, return_slices=True, u_weights=wu, v_weights=wv)
+            poison()
+            pair_a.sum().backward()
+            poison()
+            _, c_b, _ = shw.ssw_pair_losses(y2.detach(), x, U, 2, return_slices=True, u_weights=wv, v_weights=wu)
+            poison()
+            _, c_c, _ = shw.ssw_pair_losses(x, y2.detach(), U, 1, return_slices=True, u_weights=wu, v_weights=wv)
+            if not torch.allclose(c_a, c_b, rtol=2e-3, atol=2e-7):
+                problems.append(f"weighted symmetry: max rel {float(((c_a - c_b).abs() / (c_a + 1e-6)).max())}")
+            for name, t in (("weighted cost", c_a), ("weighted p1", c_c), ("weighted gx", xs.grad), ("weighted gy", y2.grad)):
+                if not bool(torch.isfinite(t).all()):
+                    problems.append(f"non-finite {name}")
         if trips % 5 == 0:
             poison()
             cd = shw.chamfer_distance(xs, ys)
             cd0 = cd[0] if isinstance(cd, (tuple, list)) else cd
             if not bool(torch.isfinite(cd0).all()):
                 problems.append("chamfer non-finite")
-            poison()
-            e = shw.sliced_wasserstein_distance(x[0], y[0], num_projection=64, p=2, device=dev)
-            if not bool(torch.isfinite(e).all()):
-                problems.append("esw non-finite")
+            if n <= 4096:                        # include/shw.h: Euclidean sliced-W takes n <= 4096
+                poison()
+                e = shw.sliced_wasserstein_distance(x[0], y[0], num_projection=64, p=2, device=dev)
+                if not bool(torch.isfinite(e).all()):
+                    problems.append("esw non-finite")
         if problems:
             bad += 1
             print("PROBLEM", kind, n, m, B, problems, flush=True)
