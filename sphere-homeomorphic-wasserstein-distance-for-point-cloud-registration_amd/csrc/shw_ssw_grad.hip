@@ -26,17 +26,24 @@ namespace shw {
 // i.e. d cost / d coordinate in ORIGINAL point order.  Every entry of the two
 // coefficient rows is written exactly once (the permutations are bijections): no zero fill, no atomics.
 // ---------------------------------------------------------------------------------------------
+// waves per SIMD asked of the register allocator: what 6 B of LDS per atom allow (160 KB per CU)
+constexpr int grad_waves_per_simd(int ept) { return ept <= 16 ? 4 : (ept == 32 ? 3 : 1); }
+
 template <int EPT, int WAVES, int PMODE, bool FULL>
-__global__ __launch_bounds__(WAVES * 64) void ssw_forward_grad_kernel(SswArgs A) {
+__global__ __launch_bounds__(WAVES * 64, grad_waves_per_simd(EPT)) void ssw_forward_grad_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave;
+  constexpr int HALF = (EPT + 1) / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // LDS per wave: sorted target coordinates (4 B), coordinates by original index / coefficient staging
-  // (4 B), sorted target original indices (2 B)  =  10 B per atom (20 KB at N = 2048)
-  float* vbuf = lds + wave * (ROW * 5 / 2);
-  float* orig = vbuf + ROW;
-  unsigned short* vidx = reinterpret_cast<unsigned short*>(orig + ROW);
+  // LDS per wave, 6 B per atom (12 KB at N = 2048 -> three waves per SIMD):
+  //   row  (4 B): coordinates by ORIGINAL index while a cloud is being sorted, then the sorted target
+  //               coordinates for the shift solve, then the staging row of the coefficient un-permutation
+  //   vidx (2 B): original indices of the sorted target
+  // The SOURCE is sorted first and stays in registers (coordinates + 16-bit index pairs) while the target
+  // is sorted, so that one row serves both clouds.
+  float* row = lds + wave * (ROW * 3 / 2);
+  unsigned short* vidx = reinterpret_cast<unsigned short*>(row + ROW);
 
   const int vid = xcd_contiguous_id(blockIdx.x, A.num_groups);
   const int s = vid * WAVES + wave;
@@ -50,70 +57,88 @@ __global__ __launch_bounds__(WAVES * 64) void ssw_forward_grad_kernel(SswArgs A)
   for (int i = 0; i < 6; ++i) U[i] = Ul[i];
 
   float u[EPT];
-  int uidx[EPT];
+  unsigned upair[HALF];                              // original indices of the sorted source, two per word
   float sum_v = 0.f, sum_u = 0.f;
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {
-    const float* X = which == 0 ? A.xt + (long)b * A.m * 3 : A.xs + (long)b * n * 3;
-    const int count = which == 0 ? A.m : n;
+    const float* X = which == 0 ? A.xs + (long)b * n * 3 : A.xt + (long)b * A.m * 3;
+    const int count = which == 0 ? n : A.m;
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const float part = sorted_with_indices<EPT>(X, count, ln, U, orig, u, uidx);
+    float val[EPT];
+    int idx[EPT];
+    const float part = sorted_with_indices<EPT>(X, count, ln, U, row, val, idx);
+    const float total = wave_sum(part, lane);
     if (which == 0) {
-      sum_v = wave_sum(part, lane);
+      sum_u = total;
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) u[r] = val[r];
+#pragma unroll
+      for (int h = 0; h < HALF; ++h)
+        upair[h] = (unsigned)idx[2 * h] | ((2 * h + 1 < EPT) ? ((unsigned)idx[(2 * h + 1) % EPT] << 16) : 0u);
+    } else {
+      sum_v = total;
+      // (every lane has gathered its exact coordinates out of `row` by now: LDS operations of a wave
+      //  execute in order)
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {
-        vbuf[r * kWave + lane] = u[r];
-        vidx[r * kWave + lane] = (unsigned short)uidx[r];
+        row[r * kWave + lane] = val[r];
+        vidx[r * kWave + lane] = (unsigned short)idx[r];
       }
-    } else {
-      sum_u = wave_sum(part, lane);
     }
   }
   __builtin_amdgcn_wave_barrier();
 
   float best;
-  const int k = solve_shift<EPT, PMODE, FULL>(u, vbuf, lane, n, sum_u, sum_v, A.p, A.p_int, best);
+  const int k = solve_shift<EPT, PMODE, FULL>(u, row, lane, n, sum_u, sum_v, A.p, A.p_int, best);
   const float inv_n = 1.f / (float)n;
   if (lane == 0) {
     A.slice_cost[s] = best * inv_n;
     if (A.slice_shift) A.slice_shift[s] = k;
   }
-  // coefficients: un-permute through the LDS staging row, then store coalesced (a direct scatter to
-  // global memory costs one address per lane per store: ~0.2 ms per launch at config 3)
+  // coefficients: g replaces u in place; un-permute through the staging row, then store coalesced (a direct
+  // scatter to global memory costs one address per lane per store: ~0.2 ms per launch at config 3)
   float* cs = A.coef_s + (long)s * n;
   float* ct = A.coef_t + (long)s * A.m;
-  float g[EPT];
-  int tslot[EPT];
+  auto target_slot = [&](int e, float& off) -> int {
+    const int q = min(e, n - 1) + k;                   // in [-n, 2n): one turn at most
+    const int turn = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
+    off = (float)turn;
+    return lds_slot<EPT>(q - turn * n);
+  };
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
-    const int e = lane * EPT + r;
-    int q = min(e, n - 1) + k;                       // in [-n, 2n): one turn at most
-    float off = 0.f;
-    if (q < 0) { q += n; off = -1.f; }
-    else if (q >= n) { q -= n; off = 1.f; }
-    tslot[r] = lds_slot<EPT>(q);
-    const float d = u[r] - (vbuf[tslot[r]] + off);
-    g[r] = dpow_abs<PMODE>(d, A.p, A.p_int) * inv_n;
-    if (e < n) orig[uidx[r]] = g[r];
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) {
-    const int i = r * kWave + lane;
-    if (i < n) cs[i] = orig[i];
+    float off;
+    const int slot = target_slot(lane * EPT + r, off);
+    const float d = u[r] - (row[slot] + off);
+    u[r] = dpow_abs<PMODE>(d, A.p, A.p_int) * inv_n;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int e = lane * EPT + r;
-    if (e < n) orig[vidx[tslot[r]]] = -g[r];
+    const int iu = (int)((r & 1) ? (upair[r / 2] >> 16) : (upair[r / 2] & 0xffffu));
+    if (e < n) row[iu] = u[r];
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int i = r * kWave + lane;
-    if (i < A.m) ct[i] = orig[i];
+    if (i < n) cs[i] = row[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    float off;
+    const int slot = target_slot(e, off);
+    if (e < n) row[vidx[slot]] = -u[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int i = r * kWave + lane;
+    if (i < A.m) ct[i] = row[i];
   }
 }
 
@@ -187,7 +212,7 @@ static int launch_forward_grad(SswArgs& A, hipStream_t stream) {
   const long groups = (total + WAVES - 1) / WAVES;
   if (groups > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)groups;
-  const size_t lds = (size_t)WAVES * (EPT * kWave * 10);
+  const size_t lds = (size_t)WAVES * (EPT * kWave * 6);
   const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
   const dim3 grid((unsigned)groups), block(WAVES * 64);
   if (A.p_int == 2) {

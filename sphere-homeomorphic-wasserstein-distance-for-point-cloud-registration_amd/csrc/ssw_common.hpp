@@ -381,6 +381,9 @@ __device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X
   {
     float key[EPT];
     part = load_coords<EPT>(X, count, lane, U, key);
+    // pin the coordinate sum HERE: left alone, the compiler sinks the 64*EPT additions below the sort and
+    // keeps every unsorted coordinate alive in a register across it
+    asm volatile("" : "+v"(part));
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
       const int i = r * kWave + lane;
@@ -390,20 +393,23 @@ __device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X
   }
   wave_sort<EPT>(pk, lane);
   __builtin_amdgcn_wave_barrier();
+  // A pad is recognised by its index field (all ones, >= count whenever pads exist), NOT by the key value:
+  // the real atom with index 64*EPT-1 and a coordinate in the top quantisation cell packs to the same word
+  // 0xffffffff when the row is full.
   bool collide = false;                                  // equal quantised coordinate on adjacent atoms?
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) {
-    // A pad is recognised by its index field (all ones, >= count whenever pads exist), NOT by the key value:
-    // the real atom with index 64*EPT-1 and a coordinate in the top quantisation cell packs to the same word
-    // 0xffffffff when the row is full.
-    idx[r] = (int)(pk[r] & PK::IDX_MASK);
-    const bool pad = idx[r] >= count;
-    val[r] = pad ? __builtin_inff() : orig[idx[r]];
-    if (r > 0) collide |= ((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0 && !pad;
-  }
   {
     const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)pk[0]);
-    collide |= (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) && (idx[EPT - 1] < count);
+    collide = (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) &&
+              ((int)(pk[EPT - 1] & PK::IDX_MASK) < count);
+  }
+#pragma unroll
+  for (int r = 1; r < EPT; ++r)
+    collide |= (((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0) && ((int)(pk[r] & PK::IDX_MASK) < count);
+  // (the packed words are dead from here on: index and gathered coordinate take their registers)
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    idx[r] = (int)(pk[r] & PK::IDX_MASK);
+    val[r] = (idx[r] >= count) ? __builtin_inff() : orig[idx[r]];
   }
   if (__builtin_amdgcn_readfirstlane((int)(__ballot(collide) != 0ull)) != 0) exact_order_fixup<EPT>(val, idx, lane);
   __builtin_amdgcn_wave_barrier();
