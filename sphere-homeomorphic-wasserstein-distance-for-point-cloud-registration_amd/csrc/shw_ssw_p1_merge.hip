@@ -1,0 +1,214 @@
+// shw_ssw_p1_merge.hip -- p == 1, loss only, max(n, m) <= 2048: the level-median closed form of
+// emd1D_circle (max_spherical_sliced_w.py:210-247; see shw_ssw_p1.hip for the formula and the reference's
+// quirks) with the MERGE done by the sorting network instead of by searches.
+//
+// One workgroup of TWO wavefronts per (pair, slice).  Wave 0 projects and sorts the source, wave 1 the
+// target, at the same time, each in registers exactly like the p != 1 kernels; the cloud a key came from is
+// recorded in its lowest mantissa bit (source 0, target 1: on equal coordinates the source atom comes first,
+// the reference's stable merge order :232-235).  One more bitonic merge level -- a flip stage between the two
+// waves through LDS, then the single-wave cross-lane and in-lane stages -- leaves the 2*64*EPT keys in merged
+// order, 64*EPT consecutive positions per wave.  From there everything is arithmetic on registers:
+//     #target atoms up to position g  = prefix sum of the tag bits (in-lane, lane scan, wave offset)
+//     level numerator                 = (#source)*(m/g) - (#target)*(n/g)      (exact integers, g = gcd)
+//     gap to the merged successor     = next key - key  (last live atom: 1 - key; [0, first atom) is not
+//                                       integrated, as in the reference)
+//     weighted median                 = integer bisection, one masked sum per step, added across the two waves
+// The binary searches of the one-wave kernel (12 LDS probes per atom) are gone: 0.96 -> 0.53 ms per launch at
+// config-3 sizes.  Clearing the tag bit moves a coordinate by at most one ulp (6e-8): the value changes by
+// less than 1e-7 relative, far inside the 1e-5 parity tolerance; the one-wave kernel (exact coordinates) still
+// serves the training path and larger clouds.
+#include "ssw_common.hpp"
+
+namespace shw {
+
+// exclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ int wave_exclusive_scan(int v, int lane) {
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __builtin_amdgcn_ds_bpermute(max(lane - d, 0) << 2, incl);
+    incl += (lane >= d) ? t : 0;
+  }
+  return incl - v;
+}
+
+__device__ __forceinline__ int wave_min_int(int v, int lane) {
+  v = min(v, as_i(lane_xor<1>(as_f(v), lane)));
+  v = min(v, as_i(lane_xor<2>(as_f(v), lane)));
+  v = min(v, as_i(lane_xor<4>(as_f(v), lane)));
+  v = min(v, as_i(lane_xor<8>(as_f(v), lane)));
+  v = min(v, as_i(lane_xor<16>(as_f(v), lane)));
+  v = min(v, as_i(lane_xor<32>(as_f(v), lane)));
+  return v;
+}
+
+#ifndef SHW_P1M_WAVES
+#define SHW_P1M_WAVES 4
+#endif
+#ifndef SHW_P1M_CHAINED
+#define SHW_P1M_CHAINED true
+#endif
+constexpr int merge_waves_per_simd(int ept) { return ept <= 16 ? 6 : SHW_P1M_WAVES; }
+
+template <int EPT>
+__global__ __launch_bounds__(128, merge_waves_per_simd(EPT)) void ssw_level_median_merge_kernel(SswArgs A, int mg,
+                                                                                               int ng,
+                                                                                               float inv_lcm) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CHUNK = EPT * kWave;                     // keys per wave
+  unsigned* buf = reinterpret_cast<unsigned*>(lds);     // [EPT][128] exchange buffer
+  // 16 words of cross-wave scratch, one slot per wave each: [0..3] median partial sums (two parities),
+  // [4,5] tag counts, [6,7] first keys, [8,9] smallest / [10,11] largest level, [12,13] gap totals, [14,15] costs
+  float* red = lds + EPT * 128;
+  int* redi = reinterpret_cast<int*>(red);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
+  const int b = s / A.slices, l = s - b * A.slices;
+  const int n = A.n, m = A.m, total_live = n + m;
+
+  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
+  float U[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+
+  // ---- project + sort: wave 0 the source, wave 1 the target -------------------------------------
+  unsigned pk[EPT];
+  {
+    const float* X = wave == 0 ? A.xs + (long)b * n * 3 : A.xt + (long)b * m * 3;
+    const int count = wave == 0 ? n : m;
+    float key[EPT];
+    load_coords<EPT, false, SHW_P1M_CHAINED>(X, count, lane, U, key);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const bool live = key[r] != __builtin_inff();       // load_coords pads with +inf; no coordinate is +inf
+      pk[r] = live ? (((unsigned)as_i(key[r]) & ~1u) | (unsigned)wave) : 0xffffffffu;
+    }
+  }
+  wave_sort<EPT>(pk, lane);
+  // ---- merge the two sorted sequences: flip stage between the waves, the rest inside each wave ----
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) buf[r * 128 + wave * 64 + lane] = pk[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const unsigned p = buf[(EPT - 1 - r) * 128 + (1 - wave) * 64 + (63 - lane)];
+    pk[r] = wave ? (pk[r] > p ? pk[r] : p) : (pk[r] < p ? pk[r] : p);
+  }
+  xlane_stages<U32Keys, EPT, 32>(pk, lane);
+  if constexpr (EPT > 1) lane_stages<U32Keys, EPT, EPT / 2>(pk);
+  // merged position of pk[r]: g = wave*CHUNK + lane*EPT + r; live iff g < n + m (pads are the largest words)
+
+  // ---- level numerators and gaps -----------------------------------------------------------------
+  const int g0 = wave * CHUNK + lane * EPT;
+  int tags_in_lane = 0;
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) tags_in_lane += (g0 + r < total_live) ? (int)(pk[r] & 1u) : 0;
+  int before = wave_exclusive_scan(tags_in_lane, lane);                  // target atoms in lower lanes
+  const int wave_tags = __builtin_amdgcn_readlane(before + tags_in_lane, 63);
+  const float first_val = as_f((int)(pk[0] & ~1u));                      // this lane's first key, for its left neighbour
+  const float next_lane_first = as_f(__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, as_i(first_val)));
+  if (lane == 0) {
+    redi[4 + wave] = wave_tags;
+    red[6 + wave] = first_val;                                           // wave 1's first key is wave 0's last successor
+  }
+  __syncthreads();
+  if (wave == 1) before += redi[4];
+  const float other_first = red[7];
+  // num[r]: level numerator after merged atom g0 + r.  val[r]: its coordinate, 1 for a pad; val[EPT]: the
+  // successor of the lane's last atom (1 past the last live atom: the reference's pad value, :237).  The gap
+  // of atom r is then val[r + 1] - val[r] (0 for pads) and is recomputed where it is needed: keeping it in
+  // registers next to num and val costs the fifth wave per SIMD.
+  int num[EPT];
+  float val[EPT + 1];
+  int lo_num = 0x7fffffff, hi_num = -0x7fffffff;
+  {
+    int cv = before;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int g = g0 + r;
+      const bool live = g < total_live;
+      cv += live ? (int)(pk[r] & 1u) : 0;
+      const int cu = g + 1 - cv;
+      num[r] = cu * mg - cv * ng;
+      val[r] = live ? as_f((int)(pk[r] & ~1u)) : 1.f;
+      lo_num = live ? min(lo_num, num[r]) : lo_num;
+      hi_num = live ? max(hi_num, num[r]) : hi_num;
+    }
+    const float nxt = (lane < 63) ? next_lane_first : other_first;   // (wave 1, lane 63: g0 + EPT >= n + m always)
+    val[EPT] = (g0 + EPT < total_live) ? nxt : 1.f;
+  }
+  float wsum = val[EPT] - val[0];                                       // the lane's gaps telescope
+  lo_num = wave_min_int(lo_num, lane);
+  hi_num = -wave_min_int(-hi_num, lane);
+  wsum = wave_sum(wsum, lane);
+  if (lane == 0) { redi[8 + wave] = lo_num; redi[10 + wave] = hi_num; red[12 + wave] = wsum; }
+  __syncthreads();
+  int lo = __builtin_amdgcn_readfirstlane(min(redi[8], redi[9]));
+  int hi = __builtin_amdgcn_readfirstlane(max(redi[10], redi[11]));
+  {
+    const float total = red[12] + red[13];
+    if (!(total >= 0.5f)) hi = lo;                   // degenerate (reference: argmin of an all-inf row = index 0)
+    hi = __builtin_amdgcn_readfirstlane(hi);
+  }
+
+  // ---- weighted median: smallest level whose cumulated gap weight reaches 0.5 (:239-245) ----------
+  int parity = 0;
+  for (int it = 0; it < 34 && lo < hi; ++it) {       // <= ceil(log2(range)) <= 32 trips; both waves agree
+    const int mid = lo + ((hi - lo) >> 1);
+    float w = 0.f;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) w += (num[r] <= mid) ? (val[r + 1] - val[r]) : 0.f;
+    w = wave_sum(w, lane);
+    if (lane == 0) red[parity * 2 + wave] = w;
+    __syncthreads();
+    const float below = red[parity * 2] + red[parity * 2 + 1];
+    if (below >= 0.5f) hi = mid; else lo = mid + 1;
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    parity ^= 1;
+  }
+  const int med = lo;
+
+  // ---- cost ------------------------------------------------------------------------------------------
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) acc += (val[r + 1] - val[r]) * (float)abs(num[r] - med);
+  acc = wave_sum(acc, lane);
+  if (lane == 0) red[14 + wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A.slice_cost[s] = (red[14] + red[15]) * inv_lcm;
+    if (A.slice_shift) A.slice_shift[s] = med;
+  }
+}
+
+template <int EPT>
+static int launch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
+  const long total = (long)A.pairs * A.slices;
+  if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  A.num_groups = (int)total;
+  const size_t lds = (size_t)(EPT * 128 + 16) * sizeof(float);
+  hipLaunchKernelGGL((ssw_level_median_merge_kernel<EPT>), dim3((unsigned)total), dim3(128), lds, stream, A, mg, ng,
+                     inv_lcm);
+  return (int)hipGetLastError();
+}
+
+// loss-only p = 1 for max(n, m) <= 2048 (called from dispatch_level_median, shw_ssw_p1.hip)
+int dispatch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
+  switch (ept_for(A.n, A.m)) {
+#ifdef SHW_DEV_ONLY_EPT
+    case SHW_DEV_ONLY_EPT: return launch_level_median_merge<SHW_DEV_ONLY_EPT>(A, mg, ng, inv_lcm, stream);
+#else
+    case 1: return launch_level_median_merge<1>(A, mg, ng, inv_lcm, stream);
+    case 2: return launch_level_median_merge<2>(A, mg, ng, inv_lcm, stream);
+    case 4: return launch_level_median_merge<4>(A, mg, ng, inv_lcm, stream);
+    case 8: return launch_level_median_merge<8>(A, mg, ng, inv_lcm, stream);
+    case 16: return launch_level_median_merge<16>(A, mg, ng, inv_lcm, stream);
+    case 32: return launch_level_median_merge<32>(A, mg, ng, inv_lcm, stream);
+#endif
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+}  // namespace shw

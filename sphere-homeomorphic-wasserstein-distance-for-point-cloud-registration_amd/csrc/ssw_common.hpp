@@ -268,7 +268,10 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
 
 // Project the cloud onto the slice's circle: lane owns points r*64 + lane (coalesced 12-byte
 // records).  Padding keys are +inf so that they sort behind every real coordinate.
-template <int EPT, bool FULL = false>
+// CHAINED: make the addresses of a chunk depend (through an empty asm) on the last coordinate of the chunk
+// before it.  Needed where the loads are not inside a loop: the compiler otherwise issues all 3*EPT loads up
+// front and the raw points take 96 registers (shw_ssw_p1_merge.hip).
+template <int EPT, bool FULL = false, bool CHAINED = false>
 __device__ __forceinline__ float load_coords(const float* __restrict__ X, int count, int lane,
                                              const float (&U)[6], float (&key)[EPT], int live_count = -1) {
   // `count` bounds the addresses (clamp), `live_count` (default: count) says how many of the 64*EPT slots are
@@ -279,6 +282,9 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
     float px[CH], py[CH], pz[CH];
+    if constexpr (CHAINED) {
+      if (r0 > 0) asm volatile("" : "+v"(lane) : "v"(key[r0 > 0 ? r0 - 1 : 0]));
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const int raw = (r0 + j) * kWave + lane;

@@ -1041,3 +1041,26 @@ def test_short_soak_of_every_kernel_family(shw):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(budget=10.0) == 0
+
+
+@pytest.mark.parametrize("n,m", [(2048, 2048), (1024, 1024), (2000, 2000), (700, 1300), (2048, 1), (1, 1), (64, 64),
+                                 (65, 63), (130, 2048), (1500, 1000), (5, 3)])
+def test_p1_merge_kernel_agrees_with_the_search_kernel_and_the_oracle(shw, n, m):
+    """p = 1, loss only: two waves per slice, merged by the sorting network (shw_ssw_p1_merge.hip); with gradients
+    requested: the one-wave search kernel (exact coordinates).  Same closed form, so the per-slice costs must agree
+    to fp32 rounding (the merge kernel clears one mantissa bit of every coordinate: <= 1 ulp), and both must match
+    the float64 restatement of the reference's emd1D_circle."""
+    from oracle import exact_shift
+    g = torch.Generator().manual_seed(1000 * n + m)
+    x, y = unit_cloud(g, n), unit_cloud(g, m)
+    U = directions(g, 12)
+    _, merged, _ = shw.ssw_pair_losses(x.cuda()[None], y.cuda()[None], U.cuda(), p=1, return_slices=True)
+    xs = x.cuda().requires_grad_(True)
+    _, searched, _ = shw.ssw_pair_losses(xs[None], y.cuda()[None], U.cuda(), p=1, return_slices=True)
+    merged, searched = merged[0].cpu().numpy(), searched[0].detach().cpu().numpy()
+    assert np.all(np.isfinite(merged))
+    assert np.all(np.abs(merged - searched) <= 2e-5 * searched + 2e-7), (merged, searched)
+    cu = exact_shift.circle_coords(x.numpy(), U.numpy())
+    cv = exact_shift.circle_coords(y.numpy(), U.numpy())
+    ref = np.array([exact_shift.w1_level_median(cu[l], cv[l]) for l in range(U.shape[0])])
+    assert np.all(np.abs(merged - ref) <= 1e-4 * ref + 2e-7), (merged, ref)

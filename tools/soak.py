@@ -3,7 +3,7 @@ that must agree with each other, with the allocator's free memory NaN-poisoned b
 of an unwritten scratch word shows.
 
   forward-only vs training kernel : per-slice costs equal to 3e-6, shifts equal (but for exact ties)
-  p = 1                           : finite, >= 0
+  p = 1                           : finite, >= 0; merge kernel (loss only) vs search kernel (training) to 1e-4
   general solver (uniform weights): equals the equal-size path to 2e-4
   backward                        : finite gradients
   Chamfer / Euclidean SW          : finite
@@ -65,13 +65,26 @@ def main(budget=None):
         poison()
         _, c_1, _ = shw.ssw_pair_losses(x, y, U, 1, return_slices=True)
         poison()
+        _, c_1g, _ = shw.ssw_pair_losses(xs, ys, U, 1, return_slices=True)     # with gradients: the search kernel
+        poison()
         pair3, c_3, _ = shw.ssw_pair_losses(xs, ys, U, 3, return_slices=True)
         problems = []
         if not torch.allclose(c_f, c_g, rtol=3e-6, atol=1e-12):          # summation orders differ by an ulp or two
             problems.append(f"forward vs training cost differ: max rel {float(((c_f - c_g).abs() / (c_f + 1e-12)).max())}")
         if float((k_f != k_g).float().mean()) > 0.01:                    # exact cost ties may pick either shift
             problems.append("forward vs training shifts differ on > 1% of the slices")
-        for name, t in (("cost", c_f), ("p1", c_1), ("p3", c_3), ("gx", xs.grad), ("gy", ys.grad)):
+        if kind != "grid" and n > 1:
+            # p = 1, merge kernel (loss only) vs search kernel (training).  The reference's formula leaves out the
+            # segment [0, first atom) but keeps the median threshold at 0.5, so its value JUMPS by (first atom)/n
+            # when the cumulated weight of a level crosses 0.5; fp32 rounding decides such slices either way in
+            # either kernel (each agrees with the float64 oracle on some of them).  Hence: all but 0.2 % of the
+            # slices to 1e-4, every slice to 3/n.  (grid: masses of exact ties across the two clouds, where the
+            # order of coordinates one ulp apart matters and the merge kernel's tag bit may change it.)
+            diff = (c_1 - c_1g).abs()
+            off = diff > 1e-4 * c_1g + 5e-7
+            if float(off.float().mean()) > 0.002 or bool((diff > 3.0 / n + 1e-5).any()):
+                problems.append(f"p=1 merge vs search kernel: {int(off.sum())} slices differ, max abs {float(diff.max())}")
+        for name, t in (("cost", c_f), ("p1", c_1), ("p1 search", c_1g), ("p3", c_3), ("gx", xs.grad), ("gy", ys.grad)):
             if not bool(torch.isfinite(t).all()):
                 problems.append(f"non-finite {name}: {int((~torch.isfinite(t)).sum())}")
         if bool((c_f < 0).any()) or bool((c_1 < 0).any()):
