@@ -224,15 +224,15 @@ static int launch_level_median(SswArgs& A, hipStream_t stream) {
 
 int dispatch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream);
 
-// SHW_P1_SEARCH_KERNEL=1 (diagnostic): keep the one-wave search kernel for the loss-only case too
+// SHW_P1_SEARCH_KERNEL=1 (diagnostic): use the one-wave search kernel at every size
 static bool p1_search_kernel_forced() {
   static const bool forced = [] { const char* e = getenv("SHW_P1_SEARCH_KERNEL"); return e && e[0] == '1'; }();
   return forced;
 }
 
 int dispatch_level_median(SswArgs& A, hipStream_t stream) {
-  if (A.coef_s == nullptr && A.n <= 2048 && A.m <= 2048 && !p1_search_kernel_forced()) {
-    // loss only: two waves per slice, merge by the sorting network (shw_ssw_p1_merge.hip)
+  if (A.n <= 2048 && A.m <= 2048 && !p1_search_kernel_forced()) {
+    // two waves per slice, merge by the sorting network (shw_ssw_p1_merge.hip)
     const int g = gcd_int(A.n, A.m);
     const int mg = A.m / g, ng = A.n / g;
     return dispatch_level_median_merge(A, mg, ng, 1.f / ((float)A.n * (float)mg), stream);

@@ -16,7 +16,16 @@
 // The binary searches of the one-wave kernel (12 LDS probes per atom) are gone: 0.96 -> 0.53 ms per launch at
 // config-3 sizes.  Clearing the tag bit moves a coordinate by at most one ulp (6e-8): the value changes by
 // less than 1e-7 relative, far inside the 1e-5 parity tolerance; the one-wave kernel (exact coordinates) still
-// serves the training path and larger clouds.
+// serves clouds above 2048 points.
+//
+// GRAD = true (training): each wave sorts its cloud WITH the permutation (packed 32-bit words + exact gather +
+// fix-up, sorted_with_indices: the exact stable order of torch.sort), parks the sorted original indices in LDS
+// (2 B per atom), and the merge proceeds on the exact coordinates' bit patterns as above.  A merged atom's rank
+// inside its own cloud is (#atoms of that cloud up to it) - 1 -- already known from the level computation -- so
+// its original index is ONE LDS read, and   d cost / d coordinate = (|level_before - med| - |level - med|) / lcm
+// (first merged atom: -|level - med| / lcm) is un-permuted through two LDS staging rows and stored coalesced:
+// every coefficient written exactly once, no atomics (rows feed ssw_backward_points_kernel).  The one-wave
+// search kernel it replaces sorted 64-bit (key, index) items: 3.5 -> see DESIGN.md ms per training step.
 #include "ssw_common.hpp"
 
 namespace shw {
@@ -50,13 +59,16 @@ __device__ __forceinline__ int wave_min_int(int v, int lane) {
 #endif
 constexpr int merge_waves_per_simd(int ept) { return ept <= 16 ? 6 : SHW_P1M_WAVES; }
 
-template <int EPT>
-__global__ __launch_bounds__(128, merge_waves_per_simd(EPT)) void ssw_level_median_merge_kernel(SswArgs A, int mg,
-                                                                                               int ng,
-                                                                                               float inv_lcm) {
+template <int EPT, bool GRAD>
+__global__ __launch_bounds__(128, GRAD ? (EPT <= 16 ? 4 : 3) : merge_waves_per_simd(EPT)) void
+ssw_level_median_merge_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CHUNK = EPT * kWave;                     // keys per wave
-  unsigned* buf = reinterpret_cast<unsigned*>(lds);     // [EPT][128] exchange buffer
+  // [EPT][128] words: exchange buffer of the merge; GRAD: before that the two clouds' coordinates by original
+  // index (sorted_with_indices), after it the two coefficient staging rows
+  unsigned* buf = reinterpret_cast<unsigned*>(lds);
+  // GRAD only, behind the 16 scratch words: original indices of the two sorted clouds, [2][CHUNK] (lds_slot layout)
+  unsigned short* sidx = reinterpret_cast<unsigned short*>(lds + EPT * 128 + 16);
   // 16 words of cross-wave scratch, one slot per wave each: [0..3] median partial sums (two parities),
   // [4,5] tag counts, [6,7] first keys, [8,9] smallest / [10,11] largest level, [12,13] gap totals, [14,15] costs
   float* red = lds + EPT * 128;
@@ -77,15 +89,27 @@ __global__ __launch_bounds__(128, merge_waves_per_simd(EPT)) void ssw_level_medi
   {
     const float* X = wave == 0 ? A.xs + (long)b * n * 3 : A.xt + (long)b * m * 3;
     const int count = wave == 0 ? n : m;
-    float key[EPT];
-    load_coords<EPT, false, SHW_P1M_CHAINED>(X, count, lane, U, key);
+    if constexpr (GRAD) {
+      float val[EPT];
+      int idx[EPT];
+      sorted_with_indices<EPT>(X, count, lane, U, lds + wave * CHUNK, val, idx);
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const bool live = key[r] != __builtin_inff();       // load_coords pads with +inf; no coordinate is +inf
-      pk[r] = live ? (((unsigned)as_i(key[r]) & ~1u) | (unsigned)wave) : 0xffffffffu;
+      for (int r = 0; r < EPT; ++r) {
+        sidx[wave * CHUNK + r * kWave + lane] = (unsigned short)idx[r];     // sorted position lane*EPT + r
+        pk[r] = (idx[r] < count) ? (((unsigned)as_i(val[r]) & ~1u) | (unsigned)wave) : 0xffffffffu;
+      }
+      __syncthreads();                                    // both clouds gathered: their rows become the exchange buffer
+    } else {
+      float key[EPT];
+      load_coords<EPT, false, SHW_P1M_CHAINED>(X, count, lane, U, key);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) {
+        const bool live = key[r] != __builtin_inff();       // load_coords pads with +inf; no coordinate is +inf
+        pk[r] = live ? (((unsigned)as_i(key[r]) & ~1u) | (unsigned)wave) : 0xffffffffu;
+      }
+      wave_sort<EPT>(pk, lane);
     }
   }
-  wave_sort<EPT>(pk, lane);
   // ---- merge the two sorted sequences: flip stage between the waves, the rest inside each wave ----
 #pragma unroll
   for (int r = 0; r < EPT; ++r) buf[r * 128 + wave * 64 + lane] = pk[r];
@@ -98,6 +122,11 @@ __global__ __launch_bounds__(128, merge_waves_per_simd(EPT)) void ssw_level_medi
   xlane_stages<U32Keys, EPT, 32>(pk, lane);
   if constexpr (EPT > 1) lane_stages<U32Keys, EPT, EPT / 2>(pk);
   // merged position of pk[r]: g = wave*CHUNK + lane*EPT + r; live iff g < n + m (pads are the largest words)
+  unsigned tagmask = 0u;                                  // GRAD: bit r = cloud of merged atom r (1 = target)
+  if constexpr (GRAD) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) tagmask |= (pk[r] & 1u) << r;
+  }
 
   // ---- level numerators and gaps -----------------------------------------------------------------
   const int g0 = wave * CHUNK + lane * EPT;
@@ -170,6 +199,36 @@ __global__ __launch_bounds__(128, merge_waves_per_simd(EPT)) void ssw_level_medi
   }
   const int med = lo;
 
+  // ---- gradient coefficients ----------------------------------------------------------------------
+  if constexpr (GRAD) {
+    float* stage = lds;                                   // [2][CHUNK]: source row, target row (by original index)
+    int cv = before;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int g = g0 + r;
+      const bool live = g < total_live;
+      const int t = (int)((tagmask >> r) & 1u);
+      cv += live ? t : 0;
+      const int rank = t ? cv - 1 : g - cv;               // position inside the atom's own sorted cloud
+      const int pred = t ? num[r] + ng : num[r] - mg;     // level before the atom's own weight
+      const float before_abs = (g == 0) ? 0.f : (float)abs(pred - med);
+      const float coef = (before_abs - (float)abs(num[r] - med)) * inv_lcm;
+      if (live) {
+        const int id = sidx[t * CHUNK + lds_slot<EPT>(rank)];
+        stage[t * CHUNK + id] = coef;
+      }
+    }
+    __syncthreads();
+    float* cs = A.coef_s + (long)s * n;
+    float* ct = A.coef_t + (long)s * m;
+#pragma unroll
+    for (int r = 0; r < EPT / 2 + (EPT == 1 ? 1 : 0); ++r) {
+      const int i = r * 128 + (int)threadIdx.x;
+      if (i < n) cs[i] = stage[i];
+      if (i < m) ct[i] = stage[CHUNK + i];
+    }
+  }
+
   // ---- cost ------------------------------------------------------------------------------------------
   float acc = 0.f;
 #pragma unroll
@@ -188,13 +247,19 @@ static int launch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, 
   const long total = (long)A.pairs * A.slices;
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
-  const size_t lds = (size_t)(EPT * 128 + 16) * sizeof(float);
-  hipLaunchKernelGGL((ssw_level_median_merge_kernel<EPT>), dim3((unsigned)total), dim3(128), lds, stream, A, mg, ng,
-                     inv_lcm);
+  if (A.coef_s != nullptr) {
+    const size_t lds = (size_t)(EPT * 128 + 16) * sizeof(float) + (size_t)2 * EPT * kWave * sizeof(unsigned short);
+    hipLaunchKernelGGL((ssw_level_median_merge_kernel<EPT, true>), dim3((unsigned)total), dim3(128), lds, stream, A, mg,
+                       ng, inv_lcm);
+  } else {
+    const size_t lds = (size_t)(EPT * 128 + 16) * sizeof(float);
+    hipLaunchKernelGGL((ssw_level_median_merge_kernel<EPT, false>), dim3((unsigned)total), dim3(128), lds, stream, A,
+                       mg, ng, inv_lcm);
+  }
   return (int)hipGetLastError();
 }
 
-// loss-only p = 1 for max(n, m) <= 2048 (called from dispatch_level_median, shw_ssw_p1.hip)
+// p = 1 for max(n, m) <= 2048, with or without coefficients (called from dispatch_level_median, shw_ssw_p1.hip)
 int dispatch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT

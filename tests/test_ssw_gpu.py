@@ -1064,3 +1064,25 @@ def test_p1_merge_kernel_agrees_with_the_search_kernel_and_the_oracle(shw, n, m)
     cv = exact_shift.circle_coords(y.numpy(), U.numpy())
     ref = np.array([exact_shift.w1_level_median(cu[l], cv[l]) for l in range(U.shape[0])])
     assert np.all(np.abs(merged - ref) <= 1e-4 * ref + 2e-7), (merged, ref)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 1000), (2048, 2048), (700, 1300), (64, 64), (3, 5)])
+def test_p1_training_kernel_gradients_against_torch_autograd_of_the_restatement(shw, n, m):
+    """p = 1 with gradients (two-wave merge kernel with indices): loss and d loss / d points against torch autograd
+    through the CPU restatement of emd1D_circle (oracle/ref_mirror.py, pinned by the G1/G4 p=1 gradient fixtures).
+    The p = 1 gradient is piecewise constant in the ORDER of the merged atoms and jumps with the median level:
+    entries are compared with the near-tie allowance of grad_close."""
+    from oracle import ref_mirror
+    g = torch.Generator().manual_seed(77 * n + m)
+    x, y = unit_cloud(g, n), unit_cloud(g, m)
+    U = directions(g, 10)
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    val = shw.sliced_cost(xs, ys, U.cuda(), p=1)
+    val.backward()
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    ref = ref_mirror.sliced_cost(xc, yc, U, p=1)
+    ref.backward()
+    assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-7
+    grad_close(xs.grad.cpu().numpy(), xc.grad.numpy(), loose=1.0)
+    grad_close(ys.grad.cpu().numpy(), yc.grad.numpy(), loose=1.0)
+    assert torch.isfinite(xs.grad).all() and torch.isfinite(ys.grad).all()
