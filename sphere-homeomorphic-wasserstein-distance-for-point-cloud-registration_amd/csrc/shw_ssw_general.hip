@@ -30,14 +30,40 @@ struct GeneralArgs {
   float* slice_theta;     // optional: the cut the solve ended on
 };
 
-// one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout
-template <int EPT>
+// one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout.
+// UNIFORM (no weights given, the reference's default 1/count): the CDF is (i+1)/count -- no array -- and every
+// search over it is arithmetic: a rank estimate from key*count, put right by one comparison each way against
+// the same closed-form levels, so that ranks and levels stay mutually consistent exactly as searchsorted on the
+// reference's cumsum is (:156-170).
+template <int EPT, bool UNIFORM = false>
 struct Side {
   const float* val;
   const float* cdf;
   int count;
+  float inv_count;                                          // 1 / count
   __device__ __forceinline__ float v(int i) const { return val[lds_slot<EPT>(i)]; }
-  __device__ __forceinline__ float c(int i) const { return cdf[lds_slot<EPT>(i)]; }
+  __device__ __forceinline__ float c(int i) const {
+    if constexpr (UNIFORM) {
+      // (i+1)/count, CORRECTLY ROUNDED, without the division sequence: q = x*RN(1/y), one exact residual, one
+      // correction (Markstein).  Correct rounding matters: when n and m share a factor, levels of the two clouds
+      // coincide as rationals ((i+1)/n == (j+1)/m) and must then coincide as floats, or the very first
+      // evaluation (theta = 0, frac = 0) sees inconsistent ties and can report a false kink.
+      const float x = (float)(i + 1), y = (float)count;
+      const float q = x * inv_count;
+      return fmaf(fmaf(-q, y, x), inv_count, q);
+    }
+    else return cdf[lds_slot<EPT>(i)];
+  }
+  // UNIFORM: number of levels < key (strict) or <= key, in closed form
+  __device__ __forceinline__ int rank(float key, bool strict) const {
+    const float t = key * (float)count;
+    int r = strict ? (int)ceilf(t) - 1 : (int)floorf(t);
+    r = min(max(r, 0), count);
+    const float up = c(min(r, count - 1)), dn = c(max(r - 1, 0));
+    const bool more = r < count && (strict ? (up < key) : (up <= key));
+    const bool less = r > 0 && !(strict ? (dn < key) : (dn <= key));
+    return r + (more ? 1 : 0) - (less ? 1 : 0);
+  }
   // number of atom VALUES < key (strict) or <= key (the p = 1 formula merges by value, not by CDF level)
   __device__ __forceinline__ int values_below(float key, bool strict) const {
     int lo = 0, hi = count;
@@ -52,6 +78,7 @@ struct Side {
   }
   // number of CDF entries < key (strict) or <= key  == torch.searchsorted(cdf, key, right = !strict)
   __device__ __forceinline__ int below(float key, bool strict) const {
+    if constexpr (UNIFORM) return rank(key, strict);
     int lo = 0, hi = count;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -64,13 +91,58 @@ struct Side {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Batched, branch-free binary searches.  The searches of one atom are a chain of dependent LDS reads (12 probes
+// at 2048 atoms); a lane owns up to 64 atoms and the first version ran their searches one after the other with
+// data-dependent loops: ~1 500 dependent LDS round trips per lane per evaluation, 25 evaluations per slice,
+// 51 ms per loss at config-3 sizes.  Here NB atoms are searched TOGETHER with a fixed trip count, so that each
+// level issues NB (or 2 NB) independent reads.
+// lower_bounds2: for every key, the number of entries < key (lt) and <= key (le) among the first `count`
+// entries of an ascending array in lds_slot layout  (= torch.searchsorted(..., right=False / True)).
+// ---------------------------------------------------------------------------------------------
+template <int EPT, bool UNIFORM, int NB>
+__device__ __forceinline__ void lower_bounds2(const Side<EPT, UNIFORM>& S, const float (&key)[NB], int (&lt)[NB],
+                                              int (&le)[NB]) {
+  if constexpr (UNIFORM) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { lt[b] = S.rank(key[b], true); le[b] = S.rank(key[b], false); }
+    return;
+  }
+  const float* arr = S.cdf;
+  const int count = S.count;
+  constexpr int P = EPT * kWave;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { lt[b] = 0; le[b] = 0; }
+#pragma unroll
+  for (int st = P / 2; st >= 1; st >>= 1) {
+    float x[NB], y[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      x[b] = arr[lds_slot<EPT>(lt[b] + st - 1)];
+      y[b] = arr[lds_slot<EPT>(le[b] + st - 1)];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      lt[b] += ((lt[b] + st - 1 < count) && (x[b] < key[b])) ? st : 0;
+      le[b] += ((le[b] + st - 1 < count) && (y[b] <= key[b])) ? st : 0;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float x = arr[lds_slot<EPT>(min(lt[b], P - 1))];
+    const float y = arr[lds_slot<EPT>(min(le[b], P - 1))];
+    lt[b] += ((lt[b] < count) && (x < key[b])) ? 1 : 0;
+    le[b] += ((le[b] < count) && (y <= key[b])) ? 1 : 0;
+  }
+}
+
 // the target after moving mass theta around the circle (reference :31-48, evaluated lazily)
-template <int EPT>
+template <int EPT, bool UNIFORM = false>
 struct Rotated {
-  Side<EPT> t;
+  Side<EPT, UNIFORM> t;
   float turns, frac;
   int start;                               // number of wrapped atoms = first atom of the rotated order
-  __device__ __forceinline__ void set(const Side<EPT>& target, float theta) {
+  __device__ __forceinline__ void set(const Side<EPT, UNIFORM>& target, float theta) {
     t = target;
     turns = floorf(theta);
     frac = theta - turns;
@@ -97,7 +169,17 @@ struct Rotated {
     return p;
   }
   // number of rotated CDF entries strictly below key  == searchsorted(v_cdf_theta_rolled, key)
+  // UNIFORM: rotated entry rho is (start + rho + 1)/m - frac, so the count is arithmetic (+- one comparison)
+  __device__ __forceinline__ int rank(float key) const {
+    const int m = t.count;
+    int r = (int)ceilf((key + frac) * (float)m) - 1 - start;
+    r = min(max(r, 0), m);
+    const bool more = r < m && cdf_at(min(r, m - 1)) < key;
+    const bool less = r > 0 && !(cdf_at(max(r - 1, 0)) < key);
+    return r + (more ? 1 : 0) - (less ? 1 : 0);
+  }
   __device__ __forceinline__ int below(float key) const {
+    if constexpr (UNIFORM) return rank(key);
     int lo = 0, hi = t.count;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -107,36 +189,80 @@ struct Rotated {
     }
     return lo;
   }
+  // the same for NB keys at once, fixed trip count (see lower_bounds2)
+  template <int NB>
+  __device__ __forceinline__ void below_batch(const float (&key)[NB], int (&cnt)[NB]) const {
+    if constexpr (UNIFORM) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) cnt[b] = rank(key[b]);
+      return;
+    }
+    constexpr int P = EPT * kWave;
+    const int m = t.count;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cnt[b] = 0;
+#pragma unroll
+    for (int st = P / 2; st >= 1; st >>= 1) {
+      float x[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) x[b] = cdf_at(min(cnt[b] + st - 1, m - 1));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) cnt[b] += ((cnt[b] + st - 1 < m) && (x[b] < key[b])) ? st : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float x = cdf_at(min(cnt[b], m - 1));
+      cnt[b] += ((cnt[b] < m) && (x < key[b])) ? 1 : 0;
+    }
+  }
 };
 
 template <int PMODE>
 __device__ __forceinline__ float powp(float d, float p, int p_int) { return pow_abs<PMODE>(d, p, p_int); }
 
 // one-sided derivatives of the cost w.r.t. theta (reference dCost, :50-63), wave-uniform results
-template <int EPT, int PMODE>
-__device__ void cut_slopes(const Side<EPT>& S, const Side<EPT>& T, float theta, int lane, float p, int p_int,
+template <int EPT, int PMODE, bool UNIFORM>
+__device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, float p, int p_int,
                            float& d_plus, float& d_minus) {
-  Rotated<EPT> R;
+  Rotated<EPT, UNIFORM> R;
   R.set(T, theta);
   const int n = S.count, m = T.count;
   float sp = 0.f, sm = 0.f;
+  constexpr int NA = EPT < 4 ? EPT : 4;                      // atoms searched together
 #pragma nounroll
-  for (int r = 0; r < EPT; ++r) {
-    const int j = lane * EPT + r;
-    if (j < m) {
-      float cdf, pos, ncdf, npos;
-      R.atom(j, cdf, pos);
-      const int jn = (j + 1 == m) ? 0 : j + 1;
-      R.atom(jn, ncdf, npos);
-      if (jn == R.start) npos += 1.f;                       // successor of the last rotated atom: first atom + 1
-      const int il = min(S.below(cdf, true), n - 1);        // left-continuous source quantile (:50-51)
-      const float al = S.v(il);
-      int ir = S.below(cdf, false);                          // right-continuous on the extended arrays (:54-57)
-      if (ir == n && S.c(0) + 1.f <= cdf) ir = n + 1;
+  for (int r0 = 0; r0 < EPT; r0 += NA) {
+    // NA + 1 consecutive atoms: atom a and its successor a + 1 (the atom after the last one is atom 0; indices
+    // past the end repeat the last atom and are masked below)
+    float wc[NA + 1], wp[NA + 1];
+    int wj[NA + 1];
+#pragma unroll
+    for (int a = 0; a <= NA; ++a) {
+      const int q = lane * EPT + r0 + a;
+      wj[a] = q < m ? q : (q == m ? 0 : m - 1);
+      R.atom(wj[a], wc[a], wp[a]);
+    }
+    float cdf[NA], pos[NA], npos[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      cdf[a] = wc[a];
+      pos[a] = wp[a];
+      npos[a] = wp[a + 1] + ((wj[a + 1] == R.start) ? 1.f : 0.f);   // successor of the last rotated atom: first + 1
+    }
+    int lt[NA], le[NA];
+    lower_bounds2<EPT, UNIFORM, NA>(S, cdf, lt, le);
+    const float c0 = S.c(0), v0 = S.v(0);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const float al = S.v(min(lt[a], n - 1));               // left-continuous source quantile (:50-51)
+      int ir = le[a];                                         // right-continuous on the extended arrays (:54-57)
+      if (ir == n && c0 + 1.f <= cdf[a]) ir = n + 1;
       ir = min(ir, n);
-      const float ar = ir < n ? S.v(ir) : S.v(0) + 1.f;
-      sp += powp<PMODE>(al - npos, p, p_int) - powp<PMODE>(al - pos, p, p_int);
-      sm += powp<PMODE>(ar - npos, p, p_int) - powp<PMODE>(ar - pos, p, p_int);
+      const float ar = ir < n ? S.v(min(ir, n - 1)) : v0 + 1.f;
+      const bool live = (lane * EPT + r0 + a) < m;
+      const float tp = powp<PMODE>(al - npos[a], p, p_int) - powp<PMODE>(al - pos[a], p, p_int);
+      const float tm = powp<PMODE>(ar - npos[a], p, p_int) - powp<PMODE>(ar - pos[a], p, p_int);
+      sp += live ? tp : 0.f;
+      sm += live ? tm : 0.f;
     }
   }
   d_plus = wave_sum_uniform(sp, lane);
@@ -145,48 +271,70 @@ __device__ void cut_slopes(const Side<EPT>& S, const Side<EPT>& T, float theta, 
 
 // transport cost at a fixed cut (reference Cost, :94-112).  GRAD: also accumulates
 // d cost / d (sorted source atom) into gs and d cost / d (sorted target atom) into gt.
-template <int EPT, int PMODE, bool GRAD>
-__device__ float cut_cost(const Side<EPT>& S, const Side<EPT>& T, float theta, int lane, float p, int p_int,
+template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
+__device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, float p, int p_int,
                           float* gs, float* gt) {
-  Rotated<EPT> R;
+  Rotated<EPT, UNIFORM> R;
   R.set(T, theta);
   const int n = S.count, m = T.count;
   float acc = 0.f;
+  constexpr int NA = EPT < 4 ? EPT : 4;                      // atoms searched together
 #pragma nounroll
-  for (int r = 0; r < EPT; ++r) {
-    const int e = lane * EPT + r;
-    if (e < n) {                                             // grid point = source CDF level A_e
-      const float g = S.c(e);
-      const int cnt = R.below(g);                            // rotated target atom active at g
-      const float b = R.pos_at(min(cnt, m));
-      const float prev_a = e > 0 ? S.c(e - 1) : 0.f;
-      const float prev_c = cnt > 0 ? R.cdf_at(cnt - 1) : 0.f;
-      const float width = g - fmaxf(prev_a, prev_c);
-      const float d = S.v(e) - b;
-      acc += width * powp<PMODE>(d, p, p_int);
-      if constexpr (GRAD) {
-        const float w = width * dpow_abs<PMODE>(d, p, p_int);
-        const int jt = (cnt >= m) ? R.start : R.source_index(cnt);
-        atomicAdd(&gs[lds_slot<EPT>(e)], w);
-        atomicAdd(&gt[lds_slot<EPT>(jt)], -w);
+  for (int r0 = 0; r0 < EPT; r0 += NA) {
+    {  // grid points = source CDF levels A_e
+      float g[NA];
+      int cnt[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) g[a] = S.c(min(lane * EPT + r0 + a, n - 1));
+      R.template below_batch<NA>(g, cnt);                    // rotated target atom active at g
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int e = lane * EPT + r0 + a;
+        const bool live = e < n;
+        const int ec = min(e, n - 1);
+        const float b = R.pos_at(min(cnt[a], m));
+        const float prev_a = ec > 0 ? S.c(ec - 1) : 0.f;
+        const float prev_c = cnt[a] > 0 ? R.cdf_at(cnt[a] - 1) : 0.f;
+        const float width = g[a] - fmaxf(prev_a, prev_c);
+        const float d = S.v(ec) - b;
+        acc += live ? width * powp<PMODE>(d, p, p_int) : 0.f;
+        if constexpr (GRAD) {
+          if (live) {
+            const float w = width * dpow_abs<PMODE>(d, p, p_int);
+            const int jt = (cnt[a] >= m) ? R.start : R.source_index(cnt[a]);
+            atomicAdd(&gs[lds_slot<EPT>(e)], w);
+            atomicAdd(&gt[lds_slot<EPT>(jt)], -w);
+          }
+        }
       }
     }
-    if (e < m) {                                             // grid point = shifted target CDF level C_e
-      float g, b;
-      R.atom(e, g, b);
-      const int rho = e >= R.start ? e - R.start : e - R.start + m;
-      const int il = min(S.below(g, true), n - 1);
-      const float a = S.v(il);
-      const int na = S.below(g, false);                      // source levels <= g sort before g in the merged grid
-      const float prev_a = na > 0 ? S.c(na - 1) : 0.f;
-      const float prev_c = rho > 0 ? R.cdf_at(rho - 1) : 0.f;
-      const float width = g - fmaxf(prev_a, prev_c);
-      const float d = a - b;
-      acc += width * powp<PMODE>(d, p, p_int);
-      if constexpr (GRAD) {
-        const float w = width * dpow_abs<PMODE>(d, p, p_int);
-        atomicAdd(&gs[lds_slot<EPT>(il)], w);
-        atomicAdd(&gt[lds_slot<EPT>(e)], -w);
+    {  // grid points = shifted target CDF levels C_e
+      float g[NA], b[NA];
+      int lt[NA], le[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) R.atom(min(lane * EPT + r0 + a, m - 1), g[a], b[a]);
+      lower_bounds2<EPT, UNIFORM, NA>(S, g, lt, le);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int e = lane * EPT + r0 + a;
+        const bool live = e < m;
+        const int ec = min(e, m - 1);
+        const int rho = ec >= R.start ? ec - R.start : ec - R.start + m;
+        const int il = min(lt[a], n - 1);
+        const float av = S.v(il);
+        const int na = le[a];                                // source levels <= g sort before g in the merged grid
+        const float prev_a = na > 0 ? S.c(na - 1) : 0.f;
+        const float prev_c = rho > 0 ? R.cdf_at(rho - 1) : 0.f;
+        const float width = g[a] - fmaxf(prev_a, prev_c);
+        const float d = av - b[a];
+        acc += live ? width * powp<PMODE>(d, p, p_int) : 0.f;
+        if constexpr (GRAD) {
+          if (live) {
+            const float w = width * dpow_abs<PMODE>(d, p, p_int);
+            atomicAdd(&gs[lds_slot<EPT>(il)], w);
+            atomicAdd(&gt[lds_slot<EPT>(e)], -w);
+          }
+        }
       }
     }
   }
@@ -212,7 +360,7 @@ __device__ __forceinline__ void sorted_cdf(float (&w)[EPT], int lane) {
 
 // project, sort (with indices), gather weights and build the CDFs of both clouds of slice s; leaves the sorted
 // values / CDFs in LDS and the sorted->original index maps in registers
-template <int EPT>
+template <int EPT, bool UNIFORM = false>
 __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int lane, float* s_val, float* s_cdf,
                                               float* t_val, float* t_cdf, float* scratch, int (&sidx)[EPT],
                                               int (&tidx)[EPT]) {
@@ -236,18 +384,23 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
     float val[EPT];
     int idx[EPT];
     sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
-    float w[EPT];
+    if constexpr (UNIFORM) {                                 // CDF = (i+1)/count in closed form: no array
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int e = lane * EPT + r;
-      const bool live = e < count;
-      w[r] = !live ? 0.f : (W ? W[(long)b * wstride + idx[r]] : 1.f / (float)count);
-    }
-    sorted_cdf<EPT>(w, lane);
+      for (int r = 0; r < EPT; ++r) dval[r * kWave + lane] = val[r];
+    } else {
+      float w[EPT];
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {                          // sorted position lane*EPT + r -> slot r*64 + lane
-      dval[r * kWave + lane] = val[r];
-      dcdf[r * kWave + lane] = w[r];
+      for (int r = 0; r < EPT; ++r) {
+        const int e = lane * EPT + r;
+        const bool live = e < count;
+        w[r] = !live ? 0.f : (W ? W[(long)b * wstride + idx[r]] : 1.f / (float)count);
+      }
+      sorted_cdf<EPT>(w, lane);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) {                        // sorted position lane*EPT + r -> slot r*64 + lane
+        dval[r * kWave + lane] = val[r];
+        dcdf[r * kWave + lane] = w[r];
+      }
     }
     if (which == 0) {
 #pragma unroll
@@ -260,40 +413,44 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
   }
 }
 
-template <int EPT, int PMODE, bool GRAD>
+template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
 __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave;
   const SswArgs& A = G.base;
   const int lane = threadIdx.x & 63;
+  // rows: sorted values of both clouds, their CDFs (weighted only), coordinates by original index (later the
+  // source gradient row), target gradient row (GRAD only)
   float* s_val = lds;
-  float* s_cdf = lds + ROW;
-  float* t_val = lds + 2 * ROW;
-  float* t_cdf = lds + 3 * ROW;
-  float* scratch = lds + 4 * ROW;                            // coordinates by original index; later gs
-  float* gt = lds + 5 * ROW;                                 // GRAD only
+  float* t_val = lds + ROW;
+  float* s_cdf = UNIFORM ? nullptr : lds + 2 * ROW;
+  float* t_cdf = UNIFORM ? nullptr : lds + 3 * ROW;
+  // (loss only: the coordinates-by-original-index row of the sort shares the source row -- the gather out of it
+  //  is complete before the sorted values are written, LDS operations of a wave execute in order)
+  float* scratch = GRAD ? lds + (UNIFORM ? 2 : 4) * ROW : s_val;
+  float* gt = scratch + ROW;                                 // GRAD only
 
   const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
   if (s >= A.pairs * A.slices) return;
   const int n = A.n, m = A.m;
   int sidx[EPT], tidx[EPT];
-  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
+  prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
 
-  Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
+  Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
 
   // ---- bisection over the cut (reference :174-205) ----------------------------------------------
   float t_lo = -1.f, t_hi = 1.f, t_mid = 0.f;
   for (int it = 0; it < 40; ++it) {                          // widths halve: 2^-25 < 1e-7 after 25 steps
     float dp, dm;
-    cut_slopes<EPT, PMODE>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
+    cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
     if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece
     if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
     if ((t_hi - t_lo) < 1e-6f / 10.f) {                      // eps / L, :189
       float dp_lo, dm_lo, dp_hi, dm_hi;
-      cut_slopes<EPT, PMODE>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, dm_lo);
-      cut_slopes<EPT, PMODE>(S, T, t_hi, lane, A.p, A.p_int, dp_hi, dm_hi);
-      const float c_lo = cut_cost<EPT, PMODE, false>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
-      const float c_hi = cut_cost<EPT, PMODE, false>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
+      cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, dm_lo);
+      cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, dp_hi, dm_hi);
+      const float c_lo = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
+      const float c_hi = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
       if (fabsf(dp_lo - dm_hi) > 1e-3f)                      // tangent intersection, :198-199
         t_mid = (c_hi - c_lo + t_lo * dp_lo - t_hi * dm_hi) / (dp_lo - dm_hi);
       break;
@@ -310,7 +467,7 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  const float cost = cut_cost<EPT, PMODE, GRAD>(S, T, t_mid, lane, A.p, A.p_int, scratch, gt);
+  const float cost = cut_cost<EPT, PMODE, GRAD, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, scratch, gt);
   if (lane == 0) {
     A.slice_cost[s] = cost;
     if (G.slice_theta) G.slice_theta[s] = t_mid;
@@ -358,7 +515,7 @@ __global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
   const int n = A.n, m = A.m;
   int sidx[EPT], tidx[EPT];
   prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
-  Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
+  Side<EPT> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
 
   float lo_lev = __builtin_inff(), hi_lev = -__builtin_inff(), total = 0.f;
 #pragma nounroll
@@ -465,14 +622,21 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
     else hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, false>), grid, block, lds1, stream, G);
     return (int)hipGetLastError();
   }
-  const size_t lds = (size_t)(grad ? 6 : 5) * EPT * kWave * sizeof(float);
-  if (A.p_int == 2) {
-    if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, 2, true>), grid, block, lds, stream, G);
-    else hipLaunchKernelGGL((ssw_general_kernel<EPT, 2, false>), grid, block, lds, stream, G);
-  } else {
-    if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, 0, true>), grid, block, lds, stream, G);
-    else hipLaunchKernelGGL((ssw_general_kernel<EPT, 0, false>), grid, block, lds, stream, G);
-  }
+  const bool uniform = G.wu == nullptr && G.wv == nullptr;   // no weights: CDFs in closed form, no searches
+  const size_t lds = (size_t)((uniform ? 2 : 4) + (grad ? 2 : 0)) * EPT * kWave * sizeof(float);
+#define SHW_LAUNCH_GENERAL(PM)                                                                                 \
+  do {                                                                                                         \
+    if (uniform) {                                                                                             \
+      if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, true, true>), grid, block, lds, stream, G);    \
+      else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, false, true>), grid, block, lds, stream, G);        \
+    } else {                                                                                                   \
+      if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, true, false>), grid, block, lds, stream, G);   \
+      else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, false, false>), grid, block, lds, stream, G);       \
+    }                                                                                                          \
+  } while (0)
+  if (A.p_int == 2) SHW_LAUNCH_GENERAL(2);
+  else SHW_LAUNCH_GENERAL(0);
+#undef SHW_LAUNCH_GENERAL
   return (int)hipGetLastError();
 }
 
