@@ -64,6 +64,18 @@ struct Side {
     const bool less = r > 0 && !(strict ? (dn < key) : (dn <= key));
     return r + (more ? 1 : 0) - (less ? 1 : 0);
   }
+  // both ranks at once.  key*count further than a few ulps from an integer decides every comparison with the
+  // (correctly rounded) levels, and then  #{< key} == #{<= key} == floor(key*count);  only the rare near-integer
+  // case -- which contains every exact tie -- takes the comparisons of rank().
+  __device__ __forceinline__ void rank2(float key, int& lt, int& le) const {
+    const float t = key * (float)count;
+    const float f = floorf(t);
+    lt = le = min(max((int)f, 0), count);
+    if (fabsf(t - rintf(t)) <= 6e-7f * fabsf(t) + 1e-7f) {
+      lt = rank(key, true);
+      le = rank(key, false);
+    }
+  }
   // number of atom VALUES < key (strict) or <= key (the p = 1 formula merges by value, not by CDF level)
   __device__ __forceinline__ int values_below(float key, bool strict) const {
     int lo = 0, hi = count;
@@ -100,16 +112,24 @@ struct Side {
 // lower_bounds2: for every key, the number of entries < key (lt) and <= key (le) among the first `count`
 // entries of an ascending array in lds_slot layout  (= torch.searchsorted(..., right=False / True)).
 // ---------------------------------------------------------------------------------------------
+template <int EPT, int NB>
+__device__ __forceinline__ void lower_bounds2_arr(const float* arr, int count, const float (&key)[NB], int (&lt)[NB],
+                                                  int (&le)[NB]);
+
 template <int EPT, bool UNIFORM, int NB>
 __device__ __forceinline__ void lower_bounds2(const Side<EPT, UNIFORM>& S, const float (&key)[NB], int (&lt)[NB],
                                               int (&le)[NB]) {
   if constexpr (UNIFORM) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { lt[b] = S.rank(key[b], true); le[b] = S.rank(key[b], false); }
-    return;
+    for (int b = 0; b < NB; ++b) S.rank2(key[b], lt[b], le[b]);
+  } else {
+    lower_bounds2_arr<EPT, NB>(S.cdf, S.count, key, lt, le);
   }
-  const float* arr = S.cdf;
-  const int count = S.count;
+}
+
+template <int EPT, int NB>
+__device__ __forceinline__ void lower_bounds2_arr(const float* arr, int count, const float (&key)[NB], int (&lt)[NB],
+                                                  int (&le)[NB]) {
   constexpr int P = EPT * kWave;
 #pragma unroll
   for (int b = 0; b < NB; ++b) { lt[b] = 0; le[b] = 0; }
@@ -172,7 +192,10 @@ struct Rotated {
   // UNIFORM: rotated entry rho is (start + rho + 1)/m - frac, so the count is arithmetic (+- one comparison)
   __device__ __forceinline__ int rank(float key) const {
     const int m = t.count;
-    int r = (int)ceilf((key + frac) * (float)m) - 1 - start;
+    const float x = (key + frac) * (float)m;
+    if (fabsf(x - rintf(x)) > 1.2e-6f * fabsf(x) + 1e-7f)     // clear of every level: ceil(x) - 1 == floor(x)
+      return min(max((int)floorf(x) - start, 0), m);
+    int r = (int)ceilf(x) - 1 - start;
     r = min(max(r, 0), m);
     const bool more = r < m && cdf_at(min(r, m - 1)) < key;
     const bool less = r > 0 && !(cdf_at(max(r - 1, 0)) < key);
@@ -250,14 +273,14 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
     }
     int lt[NA], le[NA];
     lower_bounds2<EPT, UNIFORM, NA>(S, cdf, lt, le);
-    const float c0 = S.c(0), v0 = S.v(0);
+    const float v0 = S.v(0);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
       const float al = S.v(min(lt[a], n - 1));               // left-continuous source quantile (:50-51)
-      int ir = le[a];                                         // right-continuous on the extended arrays (:54-57)
-      if (ir == n && c0 + 1.f <= cdf[a]) ir = n + 1;
-      ir = min(ir, n);
-      const float ar = ir < n ? S.v(min(ir, n - 1)) : v0 + 1.f;
+      // right-continuous on the extended arrays (:54-57): past the last source level the quantile is the first
+      // atom one turn later (the second extension, level c0 + 1, cannot be reached: cdf <= 1); unconditional read
+      const float sv = S.v(min(le[a], n - 1));
+      const float ar = le[a] < n ? sv : v0 + 1.f;
       const bool live = (lane * EPT + r0 + a) < m;
       const float tp = powp<PMODE>(al - npos[a], p, p_int) - powp<PMODE>(al - pos[a], p, p_int);
       const float tm = powp<PMODE>(ar - npos[a], p, p_int) - powp<PMODE>(ar - pos[a], p, p_int);
@@ -518,28 +541,41 @@ __global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
   Side<EPT> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
 
   float lo_lev = __builtin_inff(), hi_lev = -__builtin_inff(), total = 0.f;
+  constexpr int NA = EPT < 4 ? EPT : 4;                      // atoms searched together (see lower_bounds2)
 #pragma nounroll
-  for (int r = 0; r < EPT; ++r) {
-    const int e = lane * EPT + r;
-    if (e < n) {                                             // source atom e
-      const float val = S.v(e);
-      const int lb = T.values_below(val, true);
-      const float lev = S.c(e) - (lb > 0 ? T.c(lb - 1) : 0.f);
-      const float nxt = fminf(e + 1 < n ? S.v(e + 1) : __builtin_inff(), lb < m ? T.v(lb) : __builtin_inff());
-      const float gap = (nxt == __builtin_inff() ? 1.f : nxt) - val;
-      lev_s[r * kWave + lane] = lev;
-      gap_s[r * kWave + lane] = gap;
-      lo_lev = fminf(lo_lev, lev); hi_lev = fmaxf(hi_lev, lev); total += gap;
+  for (int r0 = 0; r0 < EPT; r0 += NA) {
+    float su[NA], sv[NA];
+    int lt_u[NA], le_u[NA], lt_v[NA], le_v[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      su[a] = S.v(min(lane * EPT + r0 + a, n - 1));
+      sv[a] = T.v(min(lane * EPT + r0 + a, m - 1));
     }
-    if (e < m) {                                             // target atom e
-      const float val = T.v(e);
-      const int ub = S.values_below(val, false);
-      const float lev = (ub > 0 ? S.c(ub - 1) : 0.f) - T.c(e);
-      const float nxt = fminf(e + 1 < m ? T.v(e + 1) : __builtin_inff(), ub < n ? S.v(ub) : __builtin_inff());
-      const float gap = (nxt == __builtin_inff() ? 1.f : nxt) - val;
-      lev_t[r * kWave + lane] = lev;
-      gap_t[r * kWave + lane] = gap;
-      lo_lev = fminf(lo_lev, lev); hi_lev = fmaxf(hi_lev, lev); total += gap;
+    lower_bounds2_arr<EPT, NA>(t_val, m, su, lt_u, le_u);    // source atom: target values <  it
+    lower_bounds2_arr<EPT, NA>(s_val, n, sv, lt_v, le_v);    // target atom: source values <= it
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int r = r0 + a, e = lane * EPT + r;
+      if (e < n) {                                           // source atom e
+        const float val = su[a];
+        const int lb = lt_u[a];
+        const float lev = S.c(e) - (lb > 0 ? T.c(lb - 1) : 0.f);
+        const float nxt = fminf(e + 1 < n ? S.v(e + 1) : __builtin_inff(), lb < m ? T.v(lb) : __builtin_inff());
+        const float gap = (nxt == __builtin_inff() ? 1.f : nxt) - val;
+        lev_s[r * kWave + lane] = lev;
+        gap_s[r * kWave + lane] = gap;
+        lo_lev = fminf(lo_lev, lev); hi_lev = fmaxf(hi_lev, lev); total += gap;
+      }
+      if (e < m) {                                           // target atom e
+        const float val = sv[a];
+        const int ub = le_v[a];
+        const float lev = (ub > 0 ? S.c(ub - 1) : 0.f) - T.c(e);
+        const float nxt = fminf(e + 1 < m ? T.v(e + 1) : __builtin_inff(), ub < n ? S.v(ub) : __builtin_inff());
+        const float gap = (nxt == __builtin_inff() ? 1.f : nxt) - val;
+        lev_t[r * kWave + lane] = lev;
+        gap_t[r * kWave + lane] = gap;
+        lo_lev = fminf(lo_lev, lev); hi_lev = fmaxf(hi_lev, lev); total += gap;
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
