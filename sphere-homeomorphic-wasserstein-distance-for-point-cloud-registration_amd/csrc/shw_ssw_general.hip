@@ -28,6 +28,9 @@ struct GeneralArgs {
   long wu_pair_stride;    // 0 = shared by all pairs
   long wv_pair_stride;
   float* slice_theta;     // optional: the cut the solve ended on
+  float first_step;       // first step of the bracket search around the mean-difference guess
+  float min_width;        // bracket width below which the tangent intersection finishes the solve
+  float grid;             // no weights: lcm(n, m) -- every kink of the cost is a multiple of 1/grid; else 0
 };
 
 // one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout.
@@ -386,7 +389,7 @@ __device__ __forceinline__ void sorted_cdf(float (&w)[EPT], int lane) {
 template <int EPT, bool UNIFORM = false>
 __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int lane, float* s_val, float* s_cdf,
                                               float* t_val, float* t_cdf, float* scratch, int (&sidx)[EPT],
-                                              int (&tidx)[EPT]) {
+                                              int (&tidx)[EPT], float& mean_s, float& mean_t) {
   const SswArgs& A = G.base;
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n, m = A.m;
@@ -406,8 +409,10 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
     asm volatile("" : "+v"(ln));
     float val[EPT];
     int idx[EPT];
-    sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
-    if constexpr (UNIFORM) {                                 // CDF = (i+1)/count in closed form: no array
+    const float part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
+    float mean = 0.f;                                        // mass-weighted mean coordinate (first guess of the cut)
+    if constexpr (UNIFORM) {
+      mean = wave_sum_uniform(part, lane) / (float)count;                                 // CDF = (i+1)/count in closed form: no array
 #pragma unroll
       for (int r = 0; r < EPT; ++r) dval[r * kWave + lane] = val[r];
     } else {
@@ -417,7 +422,9 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
         const int e = lane * EPT + r;
         const bool live = e < count;
         w[r] = !live ? 0.f : (W ? W[(long)b * wstride + idx[r]] : 1.f / (float)count);
+        mean += live ? w[r] * val[r] : 0.f;
       }
+      mean = wave_sum_uniform(mean, lane);
       sorted_cdf<EPT>(w, lane);
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {                        // sorted position lane*EPT + r -> slot r*64 + lane
@@ -425,6 +432,7 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
         dcdf[r * kWave + lane] = w[r];
       }
     }
+    if (which == 0) mean_t = mean; else mean_s = mean;
     if (which == 0) {
 #pragma unroll
       for (int r = 0; r < EPT; ++r) tidx[r] = idx[r];
@@ -457,29 +465,59 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   if (s >= A.pairs * A.slices) return;
   const int n = A.n, m = A.m;
   int sidx[EPT], tidx[EPT];
-  prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
+  float mean_s = 0.f, mean_t = 0.f;
+  prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s, mean_t);
 
   Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
 
-  // ---- bisection over the cut (reference :174-205) ----------------------------------------------
-  float t_lo = -1.f, t_hi = 1.f, t_mid = 0.f;
-  for (int it = 0; it < 40; ++it) {                          // widths halve: 2^-25 < 1e-7 after 25 steps
+  // ---- the cut: minimiser of the convex, piecewise LINEAR cost over theta in [-1, 1] -------------------
+  // The reference bisects [-1, 1] from theta = 0 on the sign of dCost until the bracket is below eps/L = 1e-7,
+  // then intersects the two end tangents (:174-205): ~27 derivative evaluations.  Same exits here (kink:
+  // dC+ * dC- <= 0; tangent intersection), but the bracket is grown around a first guess instead of halved
+  // from [-1, 1]: moving the cut by theta moves every target atom by theta, so for p = 2 the optimum is the
+  // difference of the mean coordinates (up to the kink spacing) and for other p it is near it; the search
+  // steps out from there (doubling) until dCost changes sign, then bisects.  Both quantile functions are step
+  // functions, so the cost is linear between kinks, and once the bracket is narrower than the smallest kink
+  // spacing (G.min_width: half a level of the lcm grid without weights, the reference's 1e-7 with weights) it
+  // holds at most one kink and the tangent intersection IS the minimiser.
+  float t_lo = -1.f, t_hi = 1.f;
+  float t_mid = fminf(fmaxf(mean_s - mean_t, -1.f), 1.f);
+  if (!(t_mid >= -1.f)) t_mid = 0.f;                         // non-finite input
+  bool lo_tight = false, hi_tight = false;
+  float step = G.first_step, dp_lo = 0.f, dm_hi = 0.f;
+  for (int it = 0; it < 64; ++it) {                          // <= ~25 doublings + ~25 halvings
     float dp, dm;
     cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
-    if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece
+    if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece (:186-187)
     if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
-    if ((t_hi - t_lo) < 1e-6f / 10.f) {                      // eps / L, :189
-      float dp_lo, dm_lo, dp_hi, dm_hi;
-      cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, dm_lo);
-      cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, dp_hi, dm_hi);
+    if (dp < 0.f) { t_lo = t_mid; lo_tight = true; dp_lo = dp; }
+    else { t_hi = t_mid; hi_tight = true; dm_hi = dm; }
+    if ((t_hi - t_lo) < G.min_width) {                       // :189-200
+      float unused;
+      if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, unused);
+      if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, unused, dm_hi);
       const float c_lo = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
       const float c_hi = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
-      if (fabsf(dp_lo - dm_hi) > 1e-3f)                      // tangent intersection, :198-199
-        t_mid = (c_hi - c_lo + t_lo * dp_lo - t_hi * dm_hi) / (dp_lo - dm_hi);
+      t_mid = (t_lo + t_hi) * 0.5f;
+      const float on_grid = G.grid > 0.f ? rintf(t_mid * G.grid) / G.grid : 2.f;
+      if (on_grid >= t_lo && on_grid <= t_hi) {
+        t_mid = on_grid;                                     // no weights: THE kink inside the bracket, exactly
+      } else if (fabsf(dp_lo - dm_hi) > 1e-3f) {             // tangent intersection, :198-199 (written relative to
+        // t_lo: the reference's form cancels terms of size theta * slope against each other)
+        const float t_x = t_lo + (c_hi - c_lo - dm_hi * (t_hi - t_lo)) / (dp_lo - dm_hi);
+        if (t_x >= t_lo && t_x <= t_hi) t_mid = t_x;
+      }
       break;
     }
-    if (dp < 0.f) t_lo = t_mid; else t_hi = t_mid;
-    t_mid = (t_lo + t_hi) * 0.5f;
+    if (lo_tight && hi_tight) {
+      t_mid = (t_lo + t_hi) * 0.5f;
+    } else if (dp < 0.f) {
+      t_mid = fminf(t_lo + step, t_hi);
+      step *= 2.f;
+    } else {
+      t_mid = fmaxf(t_hi - step, t_lo);
+      step *= 2.f;
+    }
   }
 
   if constexpr (GRAD) {
@@ -537,7 +575,8 @@ __global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
   if (s >= A.pairs * A.slices) return;
   const int n = A.n, m = A.m;
   int sidx[EPT], tidx[EPT];
-  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx);
+  float mean_s_unused = 0.f, mean_t_unused = 0.f;
+  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s_unused, mean_t_unused);
   Side<EPT> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
 
   float lo_lev = __builtin_inff(), hi_lev = -__builtin_inff(), total = 0.f;
@@ -676,9 +715,25 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+static int gcd_general(int a, int b) {
+  while (b) { const int t = a % b; a = b; b = t; }
+  return a;
+}
+
 int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                      float* slice_theta, hipStream_t stream) {
-  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta};
+  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0.f};
+  if (wu == nullptr && wv == nullptr) {                      // kinks sit on the grid of 1 / lcm(n, m)
+    const double lcm = (double)A.n / (double)gcd_general(A.n, A.m) * (double)A.m;
+    G.grid = lcm <= 4.0e6 ? (float)lcm : 0.f;                // (finer than 2.5e-7: leave it to the tangent step)
+    G.first_step = (float)(1.0 / lcm);
+    G.min_width = (float)(0.5 / lcm);
+    if (G.min_width < 1e-7f) G.min_width = 1e-7f;            // never tighter than the reference's eps / L
+    if (G.first_step < 1e-7f) G.first_step = 1e-7f;
+  } else {
+    G.first_step = 0.25f / (float)(A.n + A.m);
+    G.min_width = 1e-7f;                                     // eps / L, :189
+  }
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT
     case SHW_DEV_ONLY_EPT: return launch_general<SHW_DEV_ONLY_EPT>(G, stream);
