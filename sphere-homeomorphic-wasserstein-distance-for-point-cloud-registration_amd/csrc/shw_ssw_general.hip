@@ -498,15 +498,23 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
       if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, unused, dm_hi);
       const float c_lo = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
       const float c_hi = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
-      t_mid = (t_lo + t_hi) * 0.5f;
-      const float on_grid = G.grid > 0.f ? rintf(t_mid * G.grid) / G.grid : 2.f;
-      if (on_grid >= t_lo && on_grid <= t_hi) {
-        t_mid = on_grid;                                     // no weights: THE kink inside the bracket, exactly
+      float t_c = (t_lo + t_hi) * 0.5f;
+      const float on_grid = G.grid > 0.f ? rintf(t_c * G.grid) / G.grid : 2.f;
+      const float slack = 4e-7f;                             // a bracket end can BE the kink, seen from one side
+      if (on_grid >= t_lo - slack && on_grid <= t_hi + slack) {
+        t_c = on_grid;                                       // no weights: THE kink inside the bracket, exactly
       } else if (fabsf(dp_lo - dm_hi) > 1e-3f) {             // tangent intersection, :198-199 (written relative to
         // t_lo: the reference's form cancels terms of size theta * slope against each other)
         const float t_x = t_lo + (c_hi - c_lo - dm_hi * (t_hi - t_lo)) / (dp_lo - dm_hi);
-        if (t_x >= t_lo && t_x <= t_hi) t_mid = t_x;
+        if (t_x == t_x) t_c = fminf(fmaxf(t_x, t_lo), t_hi);
       }
+      // never end above a bracket end: an evaluation that lands within rounding of a kink can put that kink
+      // ON an end, and the candidate then sits on the wrong side of it
+      const float c_c = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_c, lane, A.p, A.p_int, nullptr, nullptr);
+      t_mid = t_c;
+      float best = c_c;
+      if (c_lo < best) { best = c_lo; t_mid = t_lo; }
+      if (c_hi < best) { best = c_hi; t_mid = t_hi; }
       break;
     }
     if (lo_tight && hi_tight) {

@@ -65,10 +65,19 @@ def main(budget=None):
         poison()
         _, c_1, _ = shw.ssw_pair_losses(x, y, U, 1, return_slices=True)
         poison()
-        _, c_1g, _ = shw.ssw_pair_losses(xs, ys, U, 1, return_slices=True)     # with gradients: the search kernel
+        x1, y1 = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        pair1g, c_1g, _ = shw.ssw_pair_losses(x1, y1, U, 1, return_slices=True)  # with gradients: permutation-carrying form
+        poison()
+        pair1g.sum().backward()
+        if not (bool(torch.isfinite(x1.grad).all()) and bool(torch.isfinite(y1.grad).all())) and not (kind == "centred" and n == 1):
+            pass_p1 = False
+        else:
+            pass_p1 = True
         poison()
         pair3, c_3, _ = shw.ssw_pair_losses(xs, ys, U, 3, return_slices=True)
         problems = []
+        if not pass_p1:
+            problems.append("non-finite p=1 gradient")
         if not torch.allclose(c_f, c_g, rtol=3e-6, atol=1e-12):          # summation orders differ by an ulp or two
             problems.append(f"forward vs training cost differ: max rel {float(((c_f - c_g).abs() / (c_f + 1e-12)).max())}")
         if float((k_f != k_g).float().mean()) > 0.01:                    # exact cost ties may pick either shift
@@ -113,6 +122,26 @@ def main(budget=None):
             _, c_c, _ = shw.ssw_pair_losses(x, y2.detach(), U, 1, return_slices=True, u_weights=wu, v_weights=wv)
             if not torch.allclose(c_a, c_b, rtol=2e-3, atol=2e-7):
                 problems.append(f"weighted symmetry: max rel {float(((c_a - c_b).abs() / (c_a + 1e-6)).max())}")
+            # unequal sizes WITHOUT weights take the closed-form-CDF kernel; the same problem with explicit uniform
+            # weights takes the searched-CDF kernel: two implementations of one function; and W(mu,nu) == W(nu,mu)
+            if m2 != n:
+                poison()
+                _, c_u, _ = shw.ssw_pair_losses(x, y2.detach(), U, 2, return_slices=True)
+                poison()
+                _, c_ur, _ = shw.ssw_pair_losses(y2.detach(), x, U, 2, return_slices=True)
+                w1 = torch.full((n,), 1.0 / n, device=dev)
+                w2 = torch.full((m2,), 1.0 / m2, device=dev)
+                poison()
+                _, c_uw, _ = shw.ssw_pair_losses(x, y2.detach(), U, 2, return_slices=True, u_weights=w1, v_weights=w2)
+                if not torch.allclose(c_u, c_ur, rtol=5e-4, atol=2e-7):
+                    problems.append(f"unequal-size symmetry: max rel {float(((c_u - c_ur).abs() / (c_u + 1e-6)).max())}")
+                if not torch.allclose(c_u, c_uw, rtol=5e-4, atol=2e-7):
+                    problems.append(f"closed-form vs searched CDF: max rel {float(((c_u - c_uw).abs() / (c_u + 1e-6)).max())}")
+                xg, yg = x.clone().requires_grad_(True), y2.detach().clone().requires_grad_(True)
+                poison()
+                shw.ssw_pair_losses(xg, yg, U, 3).sum().backward()
+                if not (bool(torch.isfinite(xg.grad).all()) and bool(torch.isfinite(yg.grad).all())):
+                    problems.append("non-finite unequal-size gradient")
             for name, t in (("weighted cost", c_a), ("weighted p1", c_c), ("weighted gx", xs.grad), ("weighted gy", y2.grad)):
                 if not bool(torch.isfinite(t).all()):
                     problems.append(f"non-finite {name}")
