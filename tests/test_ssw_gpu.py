@@ -1086,3 +1086,39 @@ def test_p1_training_kernel_gradients_against_torch_autograd_of_the_restatement(
     grad_close(xs.grad.cpu().numpy(), xc.grad.numpy(), loose=1.0)
     grad_close(ys.grad.cpu().numpy(), yc.grad.numpy(), loose=1.0)
     assert torch.isfinite(xs.grad).all() and torch.isfinite(ys.grad).all()
+
+
+@pytest.mark.parametrize("poison", ["nan", "inf", "zero_cloud"])
+def test_non_finite_and_degenerate_inputs_terminate_on_every_path(shw, poison):
+    """Every kernel loop has a constant bound: garbage in must give garbage out, never a hang or a fault.  NaN / inf
+    coordinates and an all-zero cloud through the equal-size, p = 1, unequal-size, weighted, Euclidean and Chamfer
+    paths, forward and backward; afterwards the same paths must still give finite values on clean inputs."""
+    g = torch.Generator().manual_seed(99)
+    n, m = 300, 257
+    x, y, y2 = unit_cloud(g, 2, n), unit_cloud(g, 2, n), unit_cloud(g, 2, m)
+    if poison == "nan":
+        x[0, 5] = float("nan"); y[1, 7, 1] = float("nan"); y2[0, 0] = float("nan")
+    elif poison == "inf":
+        x[0, 5] = float("inf"); y[1, 7, 1] = -float("inf"); y2[0, 0, 2] = float("inf")
+    else:
+        x[0] = 0.0; y2[1] = 0.0
+    U = directions(g, 2, 16).cuda()
+    w1 = torch.full((n,), 1.0 / n, device="cuda")
+    w2 = torch.rand(m, generator=g).cuda() + 0.1
+    w2 = w2 / w2.sum()
+
+    def run_all(a, b, b2):
+        for p in (2, 1, 3):
+            for second, kw in ((b, {}), (b2, {}), (b2, {"u_weights": w1, "v_weights": w2})):
+                aa, bb = a.clone().requires_grad_(True), second.clone().requires_grad_(True)
+                out = shw.ssw_pair_losses(aa, bb, U, p, **kw)
+                out.sum().backward()
+        aa, bb = a.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+        shw.chamfer_distance(aa, bb)[0].backward()
+        shw.sliced_wasserstein_distance(a[0], b[0], num_projection=8, p=2, device="cuda")
+        torch.cuda.synchronize()
+        return out
+
+    run_all(x.cuda(), y.cuda(), y2.cuda())
+    clean = run_all(unit_cloud(g, 2, n).cuda(), unit_cloud(g, 2, n).cuda(), unit_cloud(g, 2, m).cuda())
+    assert torch.isfinite(clean).all()
