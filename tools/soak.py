@@ -125,14 +125,15 @@ def main(budget=None):
             # unequal sizes WITHOUT weights take the closed-form-CDF kernel; the same problem with explicit uniform
             # weights takes the searched-CDF kernel: two implementations of one function; and W(mu,nu) == W(nu,mu)
             if m2 != n:
+                pq = (2, 3, 1.5)[trips % 3]
                 poison()
-                _, c_u, _ = shw.ssw_pair_losses(x, y2.detach(), U, 2, return_slices=True)
+                _, c_u, _ = shw.ssw_pair_losses(x, y2.detach(), U, pq, return_slices=True)
                 poison()
-                _, c_ur, _ = shw.ssw_pair_losses(y2.detach(), x, U, 2, return_slices=True)
+                _, c_ur, _ = shw.ssw_pair_losses(y2.detach(), x, U, pq, return_slices=True)
                 w1 = torch.full((n,), 1.0 / n, device=dev)
                 w2 = torch.full((m2,), 1.0 / m2, device=dev)
                 poison()
-                _, c_uw, _ = shw.ssw_pair_losses(x, y2.detach(), U, 2, return_slices=True, u_weights=w1, v_weights=w2)
+                _, c_uw, _ = shw.ssw_pair_losses(x, y2.detach(), U, pq, return_slices=True, u_weights=w1, v_weights=w2)
                 if not torch.allclose(c_u, c_ur, rtol=5e-4, atol=2e-7):
                     problems.append(f"unequal-size symmetry: max rel {float(((c_u - c_ur).abs() / (c_u + 1e-6)).max())}")
                 if not torch.allclose(c_u, c_uw, rtol=5e-4, atol=2e-7):
