@@ -134,28 +134,44 @@ template <int EPT, int NB>
 __device__ __forceinline__ void lower_bounds2_arr(const float* arr, int count, const float (&key)[NB], int (&lt)[NB],
                                                   int (&le)[NB]) {
   constexpr int P = EPT * kWave;
+  // one fixed-trip search for #{< key}; #{<= key} then differs only by the entries EQUAL to key, which two more
+  // probes count in all but degenerate inputs (three or more equal entries: a second full search, rare branch)
 #pragma unroll
-  for (int b = 0; b < NB; ++b) { lt[b] = 0; le[b] = 0; }
+  for (int b = 0; b < NB; ++b) lt[b] = 0;
 #pragma unroll
   for (int st = P / 2; st >= 1; st >>= 1) {
-    float x[NB], y[NB];
+    float x[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      x[b] = arr[lds_slot<EPT>(lt[b] + st - 1)];
-      y[b] = arr[lds_slot<EPT>(le[b] + st - 1)];
-    }
+    for (int b = 0; b < NB; ++b) x[b] = arr[lds_slot<EPT>(lt[b] + st - 1)];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      lt[b] += ((lt[b] + st - 1 < count) && (x[b] < key[b])) ? st : 0;
-      le[b] += ((le[b] + st - 1 < count) && (y[b] <= key[b])) ? st : 0;
-    }
+    for (int b = 0; b < NB; ++b) lt[b] += ((lt[b] + st - 1 < count) && (x[b] < key[b])) ? st : 0;
   }
+  bool again = false;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const float x = arr[lds_slot<EPT>(min(lt[b], P - 1))];
-    const float y = arr[lds_slot<EPT>(min(le[b], P - 1))];
     lt[b] += ((lt[b] < count) && (x < key[b])) ? 1 : 0;
-    le[b] += ((le[b] < count) && (y <= key[b])) ? 1 : 0;
+    const float e0 = arr[lds_slot<EPT>(min(lt[b], P - 1))];
+    const float e1 = arr[lds_slot<EPT>(min(lt[b] + 1, P - 1))];
+    const float e2 = arr[lds_slot<EPT>(min(lt[b] + 2, P - 1))];
+    const bool q0 = (lt[b] < count) && (e0 == key[b]);
+    const bool q1 = q0 && (lt[b] + 1 < count) && (e1 == key[b]);
+    const bool q2 = q1 && (lt[b] + 2 < count) && (e2 == key[b]);
+    le[b] = lt[b] + (q0 ? 1 : 0) + (q1 ? 1 : 0);
+    again |= q2;
+  }
+  if (again) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      int pos = 0;
+#pragma unroll
+      for (int st = P / 2; st >= 1; st >>= 1) {
+        const float y = arr[lds_slot<EPT>(pos + st - 1)];
+        pos += ((pos + st - 1 < count) && (y <= key[b])) ? st : 0;
+      }
+      const float y = arr[lds_slot<EPT>(min(pos, P - 1))];
+      le[b] = pos + (((pos < count) && (y <= key[b])) ? 1 : 0);
+    }
   }
 }
 
@@ -254,7 +270,8 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
   R.set(T, theta);
   const int n = S.count, m = T.count;
   float sp = 0.f, sm = 0.f;
-  constexpr int NA = EPT < 4 ? EPT : 4;                      // atoms searched together
+  constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
+  constexpr int NA = EPT < NA_MAX ? EPT : NA_MAX;
 #pragma nounroll
   for (int r0 = 0; r0 < EPT; r0 += NA) {
     // NA + 1 consecutive atoms: atom a and its successor a + 1 (the atom after the last one is atom 0; indices
@@ -304,7 +321,8 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
   R.set(T, theta);
   const int n = S.count, m = T.count;
   float acc = 0.f;
-  constexpr int NA = EPT < 4 ? EPT : 4;                      // atoms searched together
+  constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
+  constexpr int NA = EPT < NA_MAX ? EPT : NA_MAX;
 #pragma nounroll
   for (int r0 = 0; r0 < EPT; r0 += NA) {
     {  // grid points = source CDF levels A_e
