@@ -34,6 +34,25 @@ __global__ void kern(float* out, int iters, float seed) {
           float q = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[i + 1]), 0xB1, 0xf, 0xf, true));
           x[i] = __builtin_amdgcn_fmed3f(x[i], p, seed);
           x[i + 1] = __builtin_amdgcn_fmed3f(x[i + 1], q, seed);
+        } else if (KIND == 5) {     // gfx950 v_permlane32_swap on a register pair + min/max + swap back: the
+          // lane^32 compare-exchange of TWO keys with full-rate VALU only (4 instructions per 2 keys)
+          int a = __builtin_bit_cast(int, x[i]), b = __builtin_bit_cast(int, x[i + 1]);
+          asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+          float fa = __builtin_bit_cast(float, a), fb = __builtin_bit_cast(float, b);
+          float lo = __builtin_fminf(fa, fb), hi = __builtin_fmaxf(fa, fb);
+          a = __builtin_bit_cast(int, lo); b = __builtin_bit_cast(int, hi);
+          asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+          x[i] = __builtin_bit_cast(float, a);
+          x[i + 1] = __builtin_bit_cast(float, b);
+        } else if (KIND == 6) {     // the same with v_permlane16_swap (lane^16 ... rows of 16)
+          int a = __builtin_bit_cast(int, x[i]), b = __builtin_bit_cast(int, x[i + 1]);
+          asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+          float fa = __builtin_bit_cast(float, a), fb = __builtin_bit_cast(float, b);
+          float lo = __builtin_fminf(fa, fb), hi = __builtin_fmaxf(fa, fb);
+          a = __builtin_bit_cast(int, lo); b = __builtin_bit_cast(int, hi);
+          asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+          x[i] = __builtin_bit_cast(float, a);
+          x[i + 1] = __builtin_bit_cast(float, b);
         }
       }
     }
@@ -75,5 +94,7 @@ int main() {
   run<2>("med3", 64, 0);
   run<3>("ds_swizzle+med3", 64, 64);
   run<4>("dpp_mov+med3", 128, 0);
+  run<5>("permlane32_swap x2+minmax", 128, 0);
+  run<6>("permlane16_swap x2+minmax", 128, 0);
   return 0;
 }
