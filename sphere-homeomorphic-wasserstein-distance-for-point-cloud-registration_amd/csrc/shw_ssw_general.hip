@@ -31,6 +31,18 @@ struct GeneralArgs {
   float first_step;       // first step of the bracket search around the mean-difference guess
   float min_width;        // bracket width below which the tangent intersection finishes the solve
   float grid;             // no weights: lcm(n, m) -- every kink of the cost is a multiple of 1/grid; else 0
+  // training runs as TWO launches: the solve at the loss-only kernel's occupancy (it leaves the cut of slice s in
+  // cut_scratch[s * cut_stride] -- the first word of the slice's own coefficient row), then the gradient kernel
+  // with cut_given = 1, which skips the solve and evaluates Cost and its gradient at that cut.
+  float* cut_scratch;
+  float* cut_scratch_t;   // index hand-off only: the target coefficient rows
+  long cut_stride;
+  int cut_given;
+  // index hand-off (no weights, n, m >= 2): the solve launch also leaves the sort permutations of slice s in the
+  // slice's coefficient rows (16-bit original indices by sorted position; the cut then goes to the LAST word of the
+  // target row), and the gradient launch rebuilds the sorted coordinates from them -- a gather and a projection
+  // instead of a second pair of sorts at the gradient kernel's low occupancy.
+  int idx_handoff;
 };
 
 // one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout.
@@ -259,6 +271,12 @@ struct Rotated {
   }
 };
 
+#ifdef SHW_DEV_NO_ATOMICS   // developer timing experiment only (wrong gradients): plain stores instead of LDS atomics
+#define SHW_LDS_ADD(ptr, v) (*(ptr) = (v))
+#else
+#define SHW_LDS_ADD(ptr, v) atomicAdd((ptr), (v))
+#endif
+
 template <int PMODE>
 __device__ __forceinline__ float powp(float d, float p, int p_int) { return pow_abs<PMODE>(d, p, p_int); }
 
@@ -346,8 +364,8 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
           if (live) {
             const float w = width * dpow_abs<PMODE>(d, p, p_int);
             const int jt = (cnt[a] >= m) ? R.start : R.source_index(cnt[a]);
-            atomicAdd(&gs[lds_slot<EPT>(e)], w);
-            atomicAdd(&gt[lds_slot<EPT>(jt)], -w);
+            SHW_LDS_ADD(&gs[lds_slot<EPT>(e)], w);
+            SHW_LDS_ADD(&gt[lds_slot<EPT>(jt)], -w);
           }
         }
       }
@@ -375,8 +393,8 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
         if constexpr (GRAD) {
           if (live) {
             const float w = width * dpow_abs<PMODE>(d, p, p_int);
-            atomicAdd(&gs[lds_slot<EPT>(il)], w);
-            atomicAdd(&gt[lds_slot<EPT>(e)], -w);
+            SHW_LDS_ADD(&gs[lds_slot<EPT>(il)], w);
+            SHW_LDS_ADD(&gt[lds_slot<EPT>(e)], -w);
           }
         }
       }
@@ -462,6 +480,50 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
   }
 }
 
+// gradient launch with index hand-off: sorted coordinates of both clouds from the permutations the solve launch
+// left in the coefficient rows (same projection arithmetic as load_coords, so the values are bit-identical to
+// the ones that were sorted)
+template <int EPT>
+__device__ __forceinline__ void prepare_from_indices(const GeneralArgs& G, int s, int lane, float* s_val, float* t_val,
+                                                     int (&sidx)[EPT], int (&tidx)[EPT]) {
+  const SswArgs& A = G.base;
+  const int b = s / A.slices, l = s - b * A.slices;
+  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
+  float U[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+#pragma nounroll
+  for (int which = 0; which < 2; ++which) {
+    const int count = which == 0 ? A.m : A.n;
+    const float* X = which == 0 ? A.xt + (long)b * count * 3 : A.xs + (long)b * count * 3;
+    const unsigned short* perm = reinterpret_cast<const unsigned short*>(
+        which == 0 ? A.coef_t + (long)s * A.m : A.coef_s + (long)s * A.n);
+    float* dval = which == 0 ? t_val : s_val;
+    int idx[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int e = lane * EPT + r;
+      idx[r] = e < count ? (int)perm[min(e, count - 1)] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int e = lane * EPT + r;
+      const float px = X[3 * idx[r]], py = X[3 * idx[r] + 1], pz = X[3 * idx[r] + 2];
+      const float a = fmaf(pz, U[4], fmaf(py, U[2], fmaf(px, U[0], 0.f)));
+      const float bb = fmaf(pz, U[5], fmaf(py, U[3], fmaf(px, U[1], 0.f)));
+      dval[r * kWave + lane] = e < count ? circle_coord(a, bb) : __builtin_inff();
+    }
+    if (which == 0) {
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) tidx[r] = idx[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) sidx[r] = idx[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
 __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -484,7 +546,23 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   const int n = A.n, m = A.m;
   int sidx[EPT], tidx[EPT];
   float mean_s = 0.f, mean_t = 0.f;
-  prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s, mean_t);
+  float handed_cut = 0.f;
+  if (GRAD && UNIFORM && G.idx_handoff) {
+    handed_cut = A.coef_t[(long)s * m + (m - 1)];            // read before the rows are reused
+    prepare_from_indices<EPT>(G, s, lane, s_val, t_val, sidx, tidx);
+  } else {
+    prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s, mean_t);
+    if (!GRAD && G.idx_handoff) {                            // solve launch: leave the permutations for the gradient launch
+      unsigned short* ps = reinterpret_cast<unsigned short*>(G.cut_scratch + (long)s * n);
+      unsigned short* pt = reinterpret_cast<unsigned short*>(G.cut_scratch_t + (long)s * m);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) {
+        const int e = lane * EPT + r;
+        if (e < n) ps[e] = (unsigned short)sidx[r];
+        if (e < m) pt[e] = (unsigned short)tidx[r];
+      }
+    }
+  }
 
   Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
 
@@ -498,52 +576,59 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   // functions, so the cost is linear between kinks, and once the bracket is narrower than the smallest kink
   // spacing (G.min_width: half a level of the lcm grid without weights, the reference's 1e-7 with weights) it
   // holds at most one kink and the tangent intersection IS the minimiser.
-  float t_lo = -1.f, t_hi = 1.f;
-  float t_mid = fminf(fmaxf(mean_s - mean_t, -1.f), 1.f);
-  if (!(t_mid >= -1.f)) t_mid = 0.f;                         // non-finite input
-  bool lo_tight = false, hi_tight = false;
-  float step = G.first_step, dp_lo = 0.f, dm_hi = 0.f;
-  for (int it = 0; it < 64; ++it) {                          // <= ~25 doublings + ~25 halvings
-    float dp, dm;
-    cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
-    if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece (:186-187)
-    if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
-    if (dp < 0.f) { t_lo = t_mid; lo_tight = true; dp_lo = dp; }
-    else { t_hi = t_mid; hi_tight = true; dm_hi = dm; }
-    if ((t_hi - t_lo) < G.min_width) {                       // :189-200
-      float unused;
-      if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, unused);
-      if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, unused, dm_hi);
-      const float c_lo = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
-      const float c_hi = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
-      float t_c = (t_lo + t_hi) * 0.5f;
-      const float on_grid = G.grid > 0.f ? rintf(t_c * G.grid) / G.grid : 2.f;
-      const float slack = 4e-7f;                             // a bracket end can BE the kink, seen from one side
-      if (on_grid >= t_lo - slack && on_grid <= t_hi + slack) {
-        t_c = on_grid;                                       // no weights: THE kink inside the bracket, exactly
-      } else if (fabsf(dp_lo - dm_hi) > 1e-3f) {             // tangent intersection, :198-199 (written relative to
-        // t_lo: the reference's form cancels terms of size theta * slope against each other)
-        const float t_x = t_lo + (c_hi - c_lo - dm_hi * (t_hi - t_lo)) / (dp_lo - dm_hi);
-        if (t_x == t_x) t_c = fminf(fmaxf(t_x, t_lo), t_hi);
+  float t_mid = 0.f;
+  if (G.cut_given) {
+    t_mid = G.idx_handoff ? handed_cut : G.cut_scratch[(long)s * G.cut_stride];   // solved by the launch just before
+  } else {
+    float t_lo = -1.f, t_hi = 1.f;
+    t_mid = fminf(fmaxf(mean_s - mean_t, -1.f), 1.f);
+    if (!(t_mid >= -1.f)) t_mid = 0.f;                         // non-finite input
+    bool lo_tight = false, hi_tight = false;
+    float step = G.first_step, dp_lo = 0.f, dm_hi = 0.f;
+    for (int it = 0; it < 64; ++it) {                          // <= ~25 doublings + ~25 halvings
+      float dp, dm;
+      cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
+      if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece (:186-187)
+      if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
+      if (dp < 0.f) { t_lo = t_mid; lo_tight = true; dp_lo = dp; }
+      else { t_hi = t_mid; hi_tight = true; dm_hi = dm; }
+      if ((t_hi - t_lo) < G.min_width) {                       // :189-200
+        float unused;
+        if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, unused);
+        if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, unused, dm_hi);
+        const float c_lo = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
+        const float c_hi = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
+        float t_c = (t_lo + t_hi) * 0.5f;
+        const float on_grid = G.grid > 0.f ? rintf(t_c * G.grid) / G.grid : 2.f;
+        const float slack = 4e-7f;                             // a bracket end can BE the kink, seen from one side
+        if (on_grid >= t_lo - slack && on_grid <= t_hi + slack) {
+          t_c = on_grid;                                       // no weights: THE kink inside the bracket, exactly
+        } else if (fabsf(dp_lo - dm_hi) > 1e-3f) {             // tangent intersection, :198-199 (written relative to
+          // t_lo: the reference's form cancels terms of size theta * slope against each other)
+          const float t_x = t_lo + (c_hi - c_lo - dm_hi * (t_hi - t_lo)) / (dp_lo - dm_hi);
+          if (t_x == t_x) t_c = fminf(fmaxf(t_x, t_lo), t_hi);
+        }
+        // never end above a bracket end: an evaluation that lands within rounding of a kink can put that kink
+        // ON an end, and the candidate then sits on the wrong side of it
+        const float c_c = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_c, lane, A.p, A.p_int, nullptr, nullptr);
+        t_mid = t_c;
+        float best = c_c;
+        if (c_lo < best) { best = c_lo; t_mid = t_lo; }
+        if (c_hi < best) { best = c_hi; t_mid = t_hi; }
+        break;
       }
-      // never end above a bracket end: an evaluation that lands within rounding of a kink can put that kink
-      // ON an end, and the candidate then sits on the wrong side of it
-      const float c_c = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_c, lane, A.p, A.p_int, nullptr, nullptr);
-      t_mid = t_c;
-      float best = c_c;
-      if (c_lo < best) { best = c_lo; t_mid = t_lo; }
-      if (c_hi < best) { best = c_hi; t_mid = t_hi; }
-      break;
+      if (lo_tight && hi_tight) {
+        t_mid = (t_lo + t_hi) * 0.5f;
+      } else if (dp < 0.f) {
+        t_mid = fminf(t_lo + step, t_hi);
+        step *= 2.f;
+      } else {
+        t_mid = fmaxf(t_hi - step, t_lo);
+        step *= 2.f;
+      }
     }
-    if (lo_tight && hi_tight) {
-      t_mid = (t_lo + t_hi) * 0.5f;
-    } else if (dp < 0.f) {
-      t_mid = fminf(t_lo + step, t_hi);
-      step *= 2.f;
-    } else {
-      t_mid = fmaxf(t_hi - step, t_lo);
-      step *= 2.f;
-    }
+    if (G.idx_handoff) { if (lane == 0) G.cut_scratch_t[(long)s * m + (m - 1)] = t_mid; }
+    else if (G.cut_scratch) G.cut_scratch[(long)s * G.cut_stride] = t_mid;
   }
 
   if constexpr (GRAD) {
@@ -563,11 +648,22 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     __builtin_amdgcn_wave_barrier();
     float* cs = A.coef_s + (long)s * n;
     float* ct = A.coef_t + (long)s * m;
+    // un-permute through LDS (the value rows are dead now) and store coalesced: a direct scatter writes one
+    // 4-byte word per cache line -- 2.3 ms per launch at n=2048, m=1536, more than the whole solve
+    float* by_index_s = s_val;
+    float* by_index_t = t_val;
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
       const int e = lane * EPT + r;
-      if (e < n) cs[sidx[r]] = scratch[r * kWave + lane];
-      if (e < m) ct[tidx[r]] = gt[r * kWave + lane];
+      if (e < n) by_index_s[sidx[r]] = scratch[r * kWave + lane];
+      if (e < m) by_index_t[tidx[r]] = gt[r * kWave + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * kWave + lane;
+      if (i < n) cs[i] = by_index_s[i];
+      if (i < m) ct[i] = by_index_t[i];
     }
   }
 }
@@ -724,19 +820,34 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
     return (int)hipGetLastError();
   }
   const bool uniform = G.wu == nullptr && G.wv == nullptr;   // no weights: CDFs in closed form, no searches
-  const size_t lds = (size_t)((uniform ? 2 : 4) + (grad ? 2 : 0)) * EPT * kWave * sizeof(float);
-#define SHW_LAUNCH_GENERAL(PM)                                                                                 \
+#define SHW_LAUNCH_GENERAL(PM, GR, ARGS)                                                                       \
   do {                                                                                                         \
-    if (uniform) {                                                                                             \
-      if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, true, true>), grid, block, lds, stream, G);    \
-      else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, false, true>), grid, block, lds, stream, G);        \
-    } else {                                                                                                   \
-      if (grad) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, true, false>), grid, block, lds, stream, G);   \
-      else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, false, false>), grid, block, lds, stream, G);       \
-    }                                                                                                          \
+    const size_t lds_ = (size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave * sizeof(float);            \
+    if (uniform) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, true>), grid, block, lds_, stream, ARGS); \
+    else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, false>), grid, block, lds_, stream, ARGS);        \
   } while (0)
-  if (A.p_int == 2) SHW_LAUNCH_GENERAL(2);
-  else SHW_LAUNCH_GENERAL(0);
+  if (!grad) {
+    if (A.p_int == 2) SHW_LAUNCH_GENERAL(2, false, G);
+    else SHW_LAUNCH_GENERAL(0, false, G);
+    return (int)hipGetLastError();
+  }
+  // training: solve with the loss-only kernel (2 LDS rows, twice the waves per CU), then one gradient evaluation
+  GeneralArgs solve = G;
+  solve.base.coef_s = nullptr;
+  solve.base.coef_t = nullptr;
+  solve.cut_scratch = A.coef_s;                              // first word of each slice's own coefficient row
+  solve.cut_stride = A.n;
+  solve.cut_scratch_t = A.coef_t;
+  const int handoff = (uniform && A.n >= 2 && A.m >= 2) ? 1 : 0;
+  solve.idx_handoff = handoff;
+  GeneralArgs eval = G;
+  eval.cut_scratch = A.coef_s;
+  eval.cut_scratch_t = A.coef_t;
+  eval.cut_stride = A.n;
+  eval.cut_given = 1;
+  eval.idx_handoff = handoff;
+  if (A.p_int == 2) { SHW_LAUNCH_GENERAL(2, false, solve); SHW_LAUNCH_GENERAL(2, true, eval); }
+  else { SHW_LAUNCH_GENERAL(0, false, solve); SHW_LAUNCH_GENERAL(0, true, eval); }
 #undef SHW_LAUNCH_GENERAL
   return (int)hipGetLastError();
 }
@@ -748,7 +859,7 @@ static int gcd_general(int a, int b) {
 
 int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                      float* slice_theta, hipStream_t stream) {
-  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0.f};
+  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0.f, nullptr, nullptr, 0, 0, 0};
   if (wu == nullptr && wv == nullptr) {                      // kinks sit on the grid of 1 / lcm(n, m)
     const double lcm = (double)A.n / (double)gcd_general(A.n, A.m) * (double)A.m;
     G.grid = lcm <= 4.0e6 ? (float)lcm : 0.f;                // (finer than 2.5e-7: leave it to the tangent step)
