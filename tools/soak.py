@@ -140,9 +140,18 @@ def main(budget=None):
                     problems.append(f"closed-form vs searched CDF: max rel {float(((c_u - c_uw).abs() / (c_u + 1e-6)).max())}")
                 xg, yg = x.clone().requires_grad_(True), y2.detach().clone().requires_grad_(True)
                 poison()
-                shw.ssw_pair_losses(xg, yg, U, 3).sum().backward()
+                shw.ssw_pair_losses(xg, yg, U, pq).sum().backward()
                 if not (bool(torch.isfinite(xg.grad).all()) and bool(torch.isfinite(yg.grad).all())):
                     problems.append("non-finite unequal-size gradient")
+                # the same gradient through the searched-CDF kernel (explicit uniform weights): different launch
+                # structure (no index hand-off), same function
+                xh, yh = x.clone().requires_grad_(True), y2.detach().clone().requires_grad_(True)
+                poison()
+                shw.ssw_pair_losses(xh, yh, U, pq, u_weights=w1, v_weights=w2).sum().backward()
+                for name, ga, gb in (("source", xg.grad, xh.grad), ("target", yg.grad, yh.grad)):
+                    err = float((ga - gb).norm() / (gb.norm() + 1e-12))
+                    if not (err < 2e-2):                       # (a few slices settle on neighbouring kinks: ~1e-3)
+                        problems.append(f"unequal-size {name} gradient, closed-form vs searched CDF: rel L2 {err:.3g}")
             for name, t in (("weighted cost", c_a), ("weighted p1", c_c), ("weighted gx", xs.grad), ("weighted gy", y2.grad)):
                 if not bool(torch.isfinite(t).all()):
                     problems.append(f"non-finite {name}")
