@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SHW_ABI_VERSION 1
+#define SHW_ABI_VERSION 2 /* 2: shw_ssw_backward_points takes per-pair upstream weights */
 #define SHW_MAX_POINTS 8192 /* per cloud, per pair */
 
 /* ABI version of the loaded library (== SHW_ABI_VERSION of the header it was built from). */
@@ -94,10 +94,14 @@ int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs,
                          float* slice_cost, int32_t* slice_shift,
                          float* coef_s, float* coef_t, void* stream);
 
+/* pair_w (pairs) and total_w (1) fp32, each may be NULL: upstream gradients d loss / d pair_loss[b] and
+ * d loss / d total[0] of shw_ssw_reduce's outputs; row b of both gradients is multiplied by
+ * pair_w[b] + total_w[0] inside the kernel (a NULL term counts as 0; both NULL = 1).  Any number of pairs
+ * (batches beyond 65535 pairs go out as several launches). */
 int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
                             const float* coef_s, const float* coef_t,
                             int pairs, int n, int m, int slices, long u_pair_stride, float scale,
-                            float* grad_xs, float* grad_xt, void* stream);
+                            const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spherical sliced-Wasserstein, general circular OT: n != m and / or non-uniform weights.
@@ -122,7 +126,8 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
  * Replaces: sliced_wasserstein_distance (Wasserstein_flow_problem/Flow_cube.ipynb:280-292): projection on unit
  * directions, per-slice sort of both projected sequences, sum of |sorted difference|^p.
  *   xs, xt (pairs, n, 3) -- equal counts, as the notebook code requires; thetas (slices, 3) shared
- *   (theta_pair_stride = 0) or (pairs, slices, 3) (stride = slices*3); p >= 1; n <= 4096.
+ *   (theta_pair_stride = 0) or (pairs, slices, 3) (stride = slices*3); p >= 1; n <= 4096; pairs <= 65535
+ *   (pairs ride on gridDim.y in the two backward kernels).
  *   slice_sum (pairs*slices) out : S_l = sum_i |u_(i) - v_(i)|^p     (the notebook's outer (mean_l S_l)^(1/p)
  *                                  is host arithmetic on `slices` numbers)
  *   coef_s / coef_t (pairs*slices*n) scratch, both NULL for a value-only call : d S_l / d projection in
@@ -150,6 +155,7 @@ int shw_esw_backward_dirs(const float* xs, const float* xt, const float* coef_s,
  *   x (pairs, n, 3), y (pairs, m, 3); eps > 0; max_iter >= 0; norm_p = p of the coordinate-wise cost
  *   sum_d |x_d - y_d|^p ('L2' -> 2); cost_pow = N of the log_N variant (1 for the plain class);
  *   thresh = the convergence threshold on mean_b sum_i |u - u_old| (the reference hard-codes 1e-9).
+ *   pairs <= 65535 (gridDim.y).
  *   workspace : shw_sinkhorn_workspace_bytes(pairs, n, m) bytes of device memory (duals, statistics);
  *               after the call its first pairs*n floats hold u and the next pairs*m floats hold v.
  *   cost (pairs) out : sum_ij exp(M_ij) C_ij  (before the batch reduction and the 1/N power, host side);
@@ -172,7 +178,7 @@ int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int n, int m
  *   min_xy (pairs*n) fp32 out : min_j |x_i - y_j|^2 ;  nn_xy (pairs*n) int32 out : its argmin j
  *   min_yx (pairs*m) fp32 out : min_i |x_i - y_j|^2 ;  nn_yx (pairs*m) int32 out : its argmin i
  *   pair_loss (pairs) out : mean_i min_xy[b,i] + mean_j min_yx[b,j]   (deterministic reduction)
- * All five outputs are required (the index arrays feed shw_chamfer_backward).
+ * All five outputs are required (the index arrays feed shw_chamfer_backward).  pairs <= 65535 (gridDim.y).
  */
 int shw_chamfer_forward(const float* x, const float* y, int pairs, int n, int m,
                         float* min_xy, int32_t* nn_xy, float* min_yx, int32_t* nn_yx,

@@ -6,8 +6,10 @@ installed -- SURVEY.md 8c), runs them on explicit inputs and writes inputs + the
 as small .npz fixtures under tests/golden/.  The reference never travels to the GPU box; these
 fixtures (data only: inputs and expected outputs) do.
 
-Run:  MPLBACKEND=Agg python oracle/make_golden.py
-Fixture ids follow SURVEY.md 8c (G1..G5).
+Run:  MPLBACKEND=Agg python oracle/make_golden.py            (every fixture)
+      MPLBACKEND=Agg python oracle/make_golden.py g8 g9      (only the named ones)
+Fixture ids follow SURVEY.md 8c (G1..G5); G6/G7 were added in round 1, G8 (the phi-max wrappers) and G9 (the
+notebook's Euclidean sliced-W cell, exec'd from the .ipynb JSON) in round 2.
 """
 from __future__ import annotations
 
@@ -58,11 +60,139 @@ def per_slice_from_reference(ref, X, Y, U, p):
         return torch.stack([ref.sliced_cost(X, Y, U[l:l + 1], p=p) for l in range(U.shape[0])])
 
 
-def main():
+class LinearSphereMap(torch.nn.Module):
+    """The deterministic phi of fixture G8: x -> normalize(x W^T + b).  (The reference's own sphere maps are
+    normalising flows from a vendored package; the wrappers only ever call `self.phi(x)`.)"""
+
+    def __init__(self, W, b):
+        super().__init__()
+        self.lin = torch.nn.Linear(3, 3)
+        with torch.no_grad():
+            self.lin.weight.copy_(torch.as_tensor(W))
+            self.lin.bias.copy_(torch.as_tensor(b))
+
+    def forward(self, x):
+        return F.normalize(self.lin(x), dim=-1)
+
+
+def g8_phi_max_wrappers(ref, ref_fast):
+    """G8: the REAL max_spherical_wassersten_distance (:498-536) and _fast (_fast.py:346-380) on CPU, with a seeded
+    linear sphere map, Adam, and an SSW callable that evaluates the reference's own sliced_cost on FIXED stored
+    directions (the wrappers pass `num_projections, device` through to SSW and never look at them)."""
+    import contextlib
+    import io
+    g = torch.Generator().manual_seed(20250108)
+    B, N, L, iters, lr = 3, 96, 16, 3, 0.05
+    first = F.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
+    second = F.normalize(first @ rot_x(40).T + 0.1 * torch.randn(B, N, 3, generator=g), dim=-1)
+    W0 = torch.eye(3) + 0.3 * torch.randn(3, 3, generator=g)
+    b0 = 0.1 * torch.randn(3, generator=g)
+    U_pair, _ = torch.linalg.qr(torch.randn(L, 3, 2, generator=g))
+    U_batch, _ = torch.linalg.qr(torch.randn(B, L, 3, 2, generator=g))
+    out = {"first": _np(first), "second": _np(second), "W0": _np(W0), "b0": _np(b0), "U_pair": _np(U_pair),
+           "U_batch": _np(U_batch), "max_iter": np.int64(iters), "lr": np.float64(lr)}
+
+    def ssw_pair(a, b, num_projections, device, p=2):
+        return ref.sliced_cost(a, b, U_pair, p=p)
+
+    def ssw_batch(a, b, num_projections, device, p=2):
+        return ref_fast.sliced_cost(a, b, U_batch, p=p)
+
+    for tag, cls, fn in (("pair", ref.max_spherical_wassersten_distance, ssw_pair),
+                         ("fast", ref_fast.max_spherical_wassersten_distance_fast, ssw_batch)):
+        for mode in ("train", "test"):
+            phi = LinearSphereMap(W0, b0)
+            opt = torch.optim.Adam(phi.parameters(), lr=lr)
+            crit = cls(L, phi, fn, opt, p=2, max_iter=iters, device="cpu")
+            a = first.clone().requires_grad_(True)
+            b = second.clone().requires_grad_(True)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):            # the wrappers print ssw.item() per inner iteration
+                ssw, fa, fb = crit(a, b, train_or_test=mode)
+            opt.zero_grad()
+            ssw.sum().backward()
+            key = f"{tag}_{mode}"
+            out[f"{key}_ssw"] = _np(ssw).reshape(-1)
+            out[f"{key}_trace"] = np.array([float(t) for t in buf.getvalue().split()], dtype=np.float64)
+            out[f"{key}_W"] = _np(phi.lin.weight)
+            out[f"{key}_b"] = _np(phi.lin.bias)
+            out[f"{key}_phi_first"] = _np(fa)
+            out[f"{key}_phi_second"] = _np(fb)
+            out[f"{key}_g_first"] = _np(a.grad)
+            out[f"{key}_g_second"] = _np(b.grad)
+            out[f"{key}_gW"] = _np(phi.lin.weight.grad)
+    np.savez_compressed(os.path.join(OUT, "g8_phi_max.npz"), **out)
+
+
+def notebook_cell_namespace(path, needle):
+    """exec the SOURCE TEXT of the notebook code cell that contains `needle` (definitions only) and return its
+    namespace.  The notebook cannot be imported (its `datas` / `losses` modules are not shipped),
+    but the cell that holds the Euclidean sliced-W family is self-contained torch code."""
+    import itertools
+    import json
+    nb = json.load(open(path))
+    cell = next(c for c in nb["cells"] if c["cell_type"] == "code" and needle in "".join(c["source"]))
+    ns = {"torch": torch, "np": np, "optim": torch.optim, "nn": torch.nn, "F": F,
+          "combinations": itertools.combinations}
+    exec(compile("".join(cell["source"]), path, "exec"), ns)
+    return ns
+
+
+def g9_notebook_euclidean_sw():
+    """G9: the notebook's `sliced_wasserstein_distance` / `max_sliced_wasserstein_distance`
+    (Wasserstein_flow_problem/Flow_cube.ipynb:275-323), exec'd from the cell text.  The cell reads a GLOBAL
+    `num_projections` (set at Flow_cube.ipynb:747 to 100) instead of its `num_projection` argument: the global
+    is set to the wanted count before every call.  Directions come from the global CPU generator: the seed is
+    stored, and the directions each call drew are re-derived with the cell's own rand_projections."""
+    ns = notebook_cell_namespace("/root/reference/Wasserstein_flow_problem/Flow_cube.ipynb", "def rand_projections")
+    g = torch.Generator().manual_seed(20250109)
+    out = {}
+    for tag, n in (("n200", 200), ("n1200", 1200)):          # 1200 = the notebooks' cloud size (:200)
+        pts = torch.rand(n, 3, generator=g) * 2 - 1
+        face = torch.randint(0, 3, (n,), generator=g)
+        pts[torch.arange(n), face] = torch.randint(0, 2, (n,), generator=g).float() * 2 - 1   # cube surface
+        tgt = F.normalize(torch.randn(n, 3, generator=g), dim=-1) * 0.8 + 0.1
+        out[f"first_{tag}"], out[f"second_{tag}"] = _np(pts), _np(tgt)
+        for p in (1, 2, 3):
+            for L in (1, 50):
+                seed = 9000 + 10 * p + L
+                ns["num_projections"] = L
+                torch.manual_seed(seed)
+                theta = ns["rand_projections"](3, L)
+                a = pts.clone().requires_grad_(True)
+                torch.manual_seed(seed)
+                val = ns["sliced_wasserstein_distance"](a, tgt, num_projection=L, p=p, device="cpu")
+                val.backward()
+                key = f"{tag}_p{p}_L{L}"
+                out[f"swd_{key}"] = _np(val)
+                out[f"swd_theta_{key}"] = _np(theta)
+                out[f"swd_seed_{key}"] = np.int64(seed)
+                out[f"swd_gfirst_{key}"] = _np(a.grad)
+        for p in (2,):
+            seed = 9500 + p
+            torch.manual_seed(seed)
+            theta0 = ns["rand_projections"](3, 1)
+            torch.manual_seed(seed)
+            val = ns["max_sliced_wasserstein_distance"](pts, tgt, p=p, max_iter=10, device="cpu")
+            out[f"maxswd_{tag}_p{p}"] = _np(val)
+            out[f"maxswd_theta0_{tag}_p{p}"] = _np(theta0)
+            out[f"maxswd_seed_{tag}_p{p}"] = np.int64(seed)
+    np.savez_compressed(os.path.join(OUT, "g9_notebook_esw.npz"), **out)
+
+
+def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     ref = _load("ref_ssw", os.path.join(REF, "max_spherical_sliced_w.py"))
     ref_fast = _load("ref_ssw_fast", os.path.join(REF, "max_spherical_sliced_w_fast.py"))
     torch.set_num_threads(8)
+    if only:
+        if "g8" in only:
+            g8_phi_max_wrappers(ref, ref_fast)
+        if "g9" in only:
+            g9_notebook_euclidean_sw()
+        for f in sorted(os.listdir(OUT)):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+        return 0
 
     # ---- G1: config 1 (N=256, L=64), x-axis rotations, p in {1,2}, values + grads -------------
     g = torch.Generator().manual_seed(20250101)
@@ -219,9 +349,12 @@ def main():
     out["C_first_row"] = _np(C[0, 0])
     np.savez_compressed(os.path.join(OUT, "g7_sinkhorn.npz"), **out)
 
+    g8_phi_max_wrappers(ref, ref_fast)
+    g9_notebook_euclidean_sw()
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(tuple(sys.argv[1:])))

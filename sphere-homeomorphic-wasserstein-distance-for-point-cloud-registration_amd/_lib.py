@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SHW_LIB_PATH") or os.path.join(_HERE, "libshw_hip.so"
 CSRC = os.path.join(_HERE, "csrc")
 
 _c_f32p = ctypes.c_void_p
+ABI_VERSION = 2           # include/shw.h SHW_ABI_VERSION
 _SIGNATURES = {
     # name: (restype, argtypes)
     "shw_abi_version": (ctypes.c_int, []),
@@ -32,7 +33,8 @@ _SIGNATURES = {
                                                ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_ssw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
-                                               ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p]),
+                                               ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                                               ctypes.c_void_p]),
     "shw_esw_forward": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                        ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_esw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
@@ -77,7 +79,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)         # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.shw_abi_version() != 1:
+    if lib.shw_abi_version() != ABI_VERSION:
         raise RuntimeError("libshw_hip.so ABI version mismatch")
     _lib = lib
     return lib

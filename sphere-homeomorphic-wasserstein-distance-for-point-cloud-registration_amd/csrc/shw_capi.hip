@@ -135,7 +135,7 @@ int shw_ssw_forward(const float* xs, const float* xt, const float* dirs, int pai
   if (pairs < 0 || slices < 0 || n < 1 || m < 1 || n > SHW_MAX_POINTS || m > SHW_MAX_POINTS) return (int)hipErrorInvalidValue;
   if (!(p >= 1.f)) return (int)hipErrorInvalidValue;
   if (u_pair_stride != 0 && u_pair_stride < (long)slices * 6) return (int)hipErrorInvalidValue;
-  if (p != 1.f && n != m) return (int)hipErrorInvalidValue;       // general quantile merge: next ABI version
+  if (p != 1.f && n != m) return (int)hipErrorInvalidValue;       // n != m with p != 1: shw_ssw_forward_general
   if (pairs == 0 || slices == 0) return 0;
   shw::SswArgs A{};
   A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = slice_shift;
@@ -209,13 +209,12 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
 
 int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
                             const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride, float scale,
-                            float* grad_xs, float* grad_xt, void* stream) {
+                            const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt, void* stream) {
   if (!xs || !xt || !dirs || !coef_s || !coef_t || !grad_xs || !grad_xt) return (int)hipErrorInvalidValue;
   if (pairs < 0 || slices < 0 || n < 1 || m < 1) return (int)hipErrorInvalidValue;
   if (pairs == 0) return 0;
-  if (pairs > 65535) return (int)hipErrorInvalidValue;
-  return shw::launch_backward_points(xs, xt, dirs, coef_s, coef_t, pairs, n, m, slices, u_pair_stride, scale, grad_xs,
-                                     grad_xt, (hipStream_t)stream);
+  return shw::launch_backward_points(xs, xt, dirs, coef_s, coef_t, pairs, n, m, slices, u_pair_stride, scale, pair_w,
+                                     total_w, grad_xs, grad_xt, (hipStream_t)stream);
 }
 
 }  // extern "C"

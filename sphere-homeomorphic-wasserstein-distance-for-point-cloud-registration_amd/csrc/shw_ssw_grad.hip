@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
                                                                   const float* __restrict__ coef_s,
                                                                   const float* __restrict__ coef_t, int n, int m,
                                                                   int slices, long u_pair_stride, float scale,
+                                                                  const float* __restrict__ pair_w,
+                                                                  const float* __restrict__ total_w,
                                                                   float* __restrict__ grad_xs,
                                                                   float* __restrict__ grad_xt, int chunks_s) {
   __shared__ float part[3][4][64];
@@ -179,7 +181,11 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
   auto add = [&](float c, const float* U) {
     const float a = fmaf(pz, U[4], fmaf(py, U[2], px * U[0]));
     const float bb = fmaf(pz, U[5], fmaf(py, U[3], px * U[1]));
-    const float w = c * inv_two_pi / fmaf(a, a, bb * bb);
+    // a point whose projection on the slice plane is exactly (0, 0) (an all-zero / zero-padded point) has no
+    // angle: the reference's autograd gives it a ZERO gradient there (torch's atan2 backward masks 0/0 and
+    // F.normalize clamps the norm, :274-279), so the quotient is guarded instead of producing inf * 0 = NaN
+    const float r2 = fmaf(a, a, bb * bb);
+    const float w = r2 > 0.f ? c * inv_two_pi / r2 : 0.f;
     gx = fmaf(w, fmaf(a, U[1], -bb * U[0]), gx);
     gy = fmaf(w, fmaf(a, U[3], -bb * U[2]), gy);
     gz = fmaf(w, fmaf(a, U[5], -bb * U[4]), gz);
@@ -198,9 +204,14 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
   part[2][wave][lane] = gz;
   __syncthreads();
   if (wave == 0 && i < cnt) {
+    // upstream gradient folded in: d loss / d pair_loss[b] (+ d loss / d total[0], which every pair feeds)
+    float up = (pair_w || total_w) ? 0.f : 1.f;
+    if (pair_w) up += pair_w[b];
+    if (total_w) up += total_w[0];
+    const float sc = scale * up;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-      G[3 * i + d] = (((part[d][0][lane] + part[d][1][lane]) + part[d][2][lane]) + part[d][3][lane]) * scale;
+      G[3 * i + d] = (((part[d][0][lane] + part[d][1][lane]) + part[d][2][lane]) + part[d][3][lane]) * sc;
   }
 }
 
@@ -246,10 +257,17 @@ int dispatch_forward_grad(SswArgs& A, hipStream_t stream) {
 
 int launch_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
                            const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride,
-                           float scale, float* grad_xs, float* grad_xt, hipStream_t stream) {
+                           float scale, const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt,
+                           hipStream_t stream) {
   const int chunks_s = (n + 63) / 64, chunks_t = (m + 63) / 64;
-  hipLaunchKernelGGL(ssw_backward_points_kernel, dim3(chunks_s + chunks_t, pairs), dim3(256), 0, stream, xs, xt, dirs,
-                     coef_s, coef_t, n, m, slices, u_pair_stride, scale, grad_xs, grad_xt, chunks_s);
+  // pairs ride on gridDim.y (<= 65535): larger batches go out as several launches over pair blocks
+  for (int b0 = 0; b0 < pairs; b0 += 65535) {
+    const int nb = pairs - b0 < 65535 ? pairs - b0 : 65535;
+    hipLaunchKernelGGL(ssw_backward_points_kernel, dim3(chunks_s + chunks_t, nb), dim3(256), 0, stream,
+                       xs + (long)b0 * n * 3, xt + (long)b0 * m * 3, dirs + (long)b0 * u_pair_stride,
+                       coef_s + (long)b0 * slices * n, coef_t + (long)b0 * slices * m, n, m, slices, u_pair_stride,
+                       scale, pair_w ? pair_w + b0 : nullptr, total_w, grad_xs + (long)b0 * n * 3, grad_xt + (long)b0 * m * 3, chunks_s);
+  }
   return (int)hipGetLastError();
 }
 

@@ -451,6 +451,7 @@ int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_
                      float* slice_theta, hipStream_t stream);   // shw_ssw_general.hip  p != 1, n != m / weights
 int launch_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,
                            const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride,
-                           float scale, float* grad_xs, float* grad_xt, hipStream_t stream);
+                           float scale, const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt,
+                           hipStream_t stream);
 
 }  // namespace shw

@@ -92,6 +92,11 @@ def sharded_pair_losses(Xs, Xt, Us, p=2, mode="pairs", group=None, sync_input_gr
             partial = local_fn(Xs, Xt, Ul, p) * ((hi - lo) / L)
     else:
         raise ValueError("mode must be 'pairs' or 'slices'")
+    if hi == lo:
+        # A rank that owns no work (world > B in "pairs" mode, world > L in "slices" mode) must still take part in
+        # the backward all-reduces of _ReplicatedInput, or the other ranks wait for it until the RCCL timeout:
+        # a zero-valued dependency on the wrapped inputs keeps it in the graph with a zero gradient.
+        partial = partial + (Xs[:0].sum() + Xt[:0].sum())
     return _SumAcrossRanks.apply(partial, group)
 
 

@@ -26,7 +26,7 @@ def rand_projections(dim, num_projections=100):
 
 class _SliceSums(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Xs, Xt, thetas, p):
+    def forward(ctx, Xs, Xt, thetas, p, need_grad=True):
         lib = _lib.load()
         B, n, _ = Xs.shape
         L = thetas.shape[-2]
@@ -34,7 +34,7 @@ class _SliceSums(torch.autograd.Function):
         xs, xt, th = Xs.contiguous(), Xt.contiguous(), thetas.contiguous()
         stride = 0 if th.dim() == 2 else L * 3
         sums = torch.empty(B * L, dtype=torch.float32, device=dev)
-        need = Xs.requires_grad or Xt.requires_grad or thetas.requires_grad
+        need = need_grad
         cs = ct = None
         if need:
             cs = torch.empty(B * L * n, dtype=torch.float32, device=dev)
@@ -71,7 +71,7 @@ class _SliceSums(torch.autograd.Function):
                            "shw_esw_backward_dirs")
                 if len(ctx.theta_shape) == 2:          # directions shared by the pairs
                     gth = gth.sum(0)
-        return gxs, gxt, gth, None
+        return gxs, gxt, gth, None, None
 
 
 def esw_slice_sums(Xs, Xt, thetas, p=2):
@@ -82,7 +82,8 @@ def esw_slice_sums(Xs, Xt, thetas, p=2):
         raise ValueError("the Euclidean sliced distance needs two (B,n,3) clouds of equal size")
     if not thetas.is_cuda or thetas.dtype != torch.float32 or thetas.shape[-1] != 3:
         raise TypeError("thetas must be a float32 device tensor (L,3) or (B,L,3)")
-    return _SliceSums.apply(Xs, Xt, thetas, float(p))
+    need = torch.is_grad_enabled() and (Xs.requires_grad or Xt.requires_grad or thetas.requires_grad)
+    return _SliceSums.apply(Xs, Xt, thetas, float(p), need)
 
 
 def sliced_wasserstein_distance(first_samples, second_samples, num_projection=100, p=2, device="cuda"):

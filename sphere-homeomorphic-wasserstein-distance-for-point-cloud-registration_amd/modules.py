@@ -6,6 +6,9 @@
 * `max_spherical_wassersten_distance` / `_fast` -- the adversarial phi-max wrappers
   (max_spherical_sliced_w.py:498-536, _fast.py:346-380): `forward(first, second, train_or_test) ->
   (ssw, phi(first), phi(second))`.
+* `max_cos_disimilarity_wassersten_distance` -- the LIVE trainer criterion (s2_wasserstein.py:211-262, built at
+  train_W_COS.py:404) with its injected `CSW` slot: phi-max inner loop with the |norm - 1| regulariser, then the
+  distance on the non-detached clouds.  Host-side Python only; `SlicedSphereW` goes in the CSW slot.
 * `SSWCriterion` / `ChamferCriterion` -- the trainer-level `criteria(template, transformed_source, ...)`
   slots (train_W_COS.py:133,171; train_CD.py:123,161).
 """
@@ -44,7 +47,7 @@ def _sum_over_pairs(SSW, first, second, num_projections, device, p):
     are evaluated by ONE batched launch instead of B."""
     if SSW is sliced_wasserstein_sphere:
         U = torch.stack([draw_directions(num_projections, device, d=first.shape[-1]) for _ in range(first.shape[0])])
-        return ssw_pair_losses(first, second, U, p).sum()
+        return ssw_pair_losses(first, second, U, p, return_total=True)[1].reshape(())
     ssw = 0
     for i in range(len(first)):
         ssw = ssw + SSW(first[i], second[i], num_projections, device, p=p)
@@ -58,6 +61,7 @@ class max_spherical_wassersten_distance(nn.Module):
         super().__init__()
         self.num_projections, self.phi, self.SSW, self.phi_op = num_projections, phi, SSW, phi_op
         self.p, self.max_iter, self.device, self.verbose = p, max_iter, device, verbose
+        self.on_inner_value = None       # optional observer of the per-iteration ssw (the reference prints it, :524)
 
     def _ssw(self, a, b):
         return _sum_over_pairs(self.SSW, a, b, self.num_projections, self.device, self.p)
@@ -73,6 +77,8 @@ class max_spherical_wassersten_distance(nn.Module):
                 self.phi_op.step()
                 if self.verbose:
                     print(ssw.item())
+                if self.on_inner_value is not None:
+                    self.on_inner_value(float(ssw.detach().sum()))
         elif train_or_test != "test":
             raise ValueError("train_or_test must be 'train' or 'test'")
         first_t, second_t = self.phi(first_samples), self.phi(second_samples)
@@ -84,6 +90,45 @@ class max_spherical_wassersten_distance_fast(max_spherical_wassersten_distance):
 
     def _ssw(self, a, b):
         return self.SSW(a, b, self.num_projections, self.device, p=self.p)
+
+
+class max_cos_disimilarity_wassersten_distance(nn.Module):
+    """The criterion train_W_COS.py:404 builds (s2_wasserstein.py:211-262): `criteria(template, transformed_source,
+    train_or_test=...) -> (cswd, phi(template), phi(source))`.  Same constructor arguments; `CSW` is any
+    `CSW(x, y) -> scalar` module -- the reference passes its exact-EMD `Cos_disimilarity_W` (POT, out of scope),
+    the drop-in passes `SlicedSphereW`.  The s2_wasserstein module itself cannot be imported without POT, so this
+    mirror is checked against a restatement (oracle/phi_max_mirror.py): parity unpinned by fixtures."""
+
+    def __init__(self, phi, CSW, device, phi_op, max_iter=10, lam=0.1, psi_minibatch_size=5):
+        super().__init__()
+        self.phi, self.CSW, self.phi_op = phi, CSW, phi_op
+        self.max_iter, self.device, self.reg_lam = max_iter, device, lam
+
+    @staticmethod
+    def regularization_of_normalizing_flow(x):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        return torch.sum(torch.abs(torch.linalg.vector_norm(x, dim=-1) - 1))           # :222-230
+
+    def forward(self, first_samples, second_samples, train_or_test="train"):
+        first_detach, second_detach = first_samples.detach(), second_samples.detach()
+        if train_or_test == "train":
+            self.phi.train()
+            for _ in range(self.max_iter):
+                self.phi_op.zero_grad()
+                a, b = self.phi(first_detach), self.phi(second_detach)
+                cswd = self.CSW(a, b)
+                reg = self.reg_lam * (self.regularization_of_normalizing_flow(a) / (a.shape[0] * a.shape[1])
+                                      + self.regularization_of_normalizing_flow(b) / (b.shape[0] * b.shape[1]))
+                loss = reg - cswd                                                    # gradient ascent (:249)
+                loss.backward(retain_graph=True)
+                self.phi_op.step()
+        elif train_or_test == "test":
+            self.phi.eval()
+        else:
+            raise ValueError("train_or_test must be 'train' or 'test'")
+        a, b = self.phi(first_samples), self.phi(second_samples)
+        return self.CSW(a, b), a, b
 
 
 class SSWCriterion(nn.Module):
@@ -110,4 +155,5 @@ class ChamferCriterion(nn.Module):
 
 
 __all__ = ["SlicedSphereW", "max_spherical_wassersten_distance", "max_spherical_wassersten_distance_fast",
+           "max_cos_disimilarity_wassersten_distance",
            "SSWCriterion", "ChamferCriterion", "sliced_wasserstein_sphere", "sliced_wasserstein_sphere_fast"]

@@ -60,11 +60,80 @@ def stiefel_frames(Z):
     return U
 
 
+class SSWWorkspace:
+    """Persistent device buffers of one problem shape (B, n, m, L): the per-slice costs and shifts / cuts and --
+    for training -- the two coefficient scratch rows that the slice kernel writes and the point-gradient kernel
+    streams (2 x 268 MB at config 3).  Instances are leased from a small pool keyed by (device, stream,
+    shape) and come back when the evaluation that used them is over: at once for a loss-only call, and when the
+    autograd node of a training call dies (after its backward, or when its graph is dropped) -- see `_Lease`.
+    A phi-max inner loop (max_iter + 1 evaluations of one shape per step, _fast.py:359-377) thus alternates
+    between two sets of buffers instead of asking the allocator for five tensors per evaluation, and nothing is
+    zero-filled.  The user-visible results (per-pair losses, total) are NOT pool memory: they are one fresh
+    (B+2)-float tensor per call, so holding on to a loss value across later calls is safe.
+    Work on the buffers is ordered by the stream they were leased on (the stream is part of the key).  While
+    a HIP graph is being captured the pool is bypassed: buffers then belong to the graph's private memory."""
+
+    _pools: dict = {}
+    MAX_IDLE_PER_KEY = 2
+
+    def __init__(self, key):
+        dev, _stream, B, n, m, L, with_coef = key
+        self.key = key
+        self.pooled = True
+        self.slice_cost = torch.empty(B * L, dtype=torch.float32, device=dev)
+        self.slice_aux = torch.empty(B * L, dtype=torch.int32, device=dev)     # shift k* / median level / cut bits
+        self.coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev) if with_coef else None
+        self.coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev) if with_coef else None
+
+    @classmethod
+    def lease(cls, dev, B, n, m, L, with_coef):
+        key = (torch.device(dev), _stream_ptr(dev), B, n, m, L, bool(with_coef))
+        if torch.cuda.is_current_stream_capturing():
+            ws = cls(key)
+            ws.pooled = False
+            return ws
+        idle = cls._pools.get(key)
+        if idle:
+            return idle.pop()
+        return cls(key)
+
+    def release(self):
+        if not self.pooled:
+            return
+        idle = SSWWorkspace._pools.setdefault(self.key, [])
+        if len(idle) < SSWWorkspace.MAX_IDLE_PER_KEY and all(ws is not self for ws in idle):
+            idle.append(self)
+
+    @classmethod
+    def clear(cls):
+        """Drop every idle buffer (hands the memory back to torch's caching allocator)."""
+        cls._pools.clear()
+
+
+class _Lease:
+    """Ties a leased workspace to the lifetime of the autograd node that reads it in backward: the node keeps the
+    lease, and when the node is freed (CPython reference counting: after backward once the loss tensor is
+    re-bound or deleted, or when a graph is dropped without backward) the buffers return to the pool.  A graph kept
+    alive with retain_graph=True keeps its buffers -- a second backward through it reads intact coefficients."""
+
+    __slots__ = ("ws",)
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __del__(self):
+        try:
+            self.ws.release()
+        except Exception:        # interpreter shutdown
+            pass
+
+
 class _PairLosses(torch.autograd.Function):
-    """(B,n,3), (B,m,3), dirs -> (B,) per-pair mean over slices of the circular OT cost W_p^p."""
+    """(B,n,3), (B,m,3), dirs -> (B,) per-pair mean over slices of the circular OT cost W_p^p, their sum (1,), and
+    on request the (B,L) per-slice costs and shifts."""
 
     @staticmethod
-    def forward(ctx, Xs, Xt, Us, p, shared_dirs, wu, wv):
+    def forward(ctx, Xs, Xt, Us, p, shared_dirs, wu, wv, need_grad, want_slices):
         lib = _lib.load()
         B, n, _ = Xs.shape
         m = Xt.shape[1]
@@ -72,21 +141,16 @@ class _PairLosses(torch.autograd.Function):
         dev = Xs.device
         Xs_c, Xt_c, Us_c = Xs.contiguous(), Xt.contiguous(), Us.contiguous()
         stride = 0 if shared_dirs else L * 6
-        slice_cost = torch.empty(B * L, dtype=torch.float32, device=dev)
-        slice_shift = torch.empty(B * L, dtype=torch.int32, device=dev)
-        pair_loss = torch.empty(B, dtype=torch.float32, device=dev)
-        need_grad = Xs.requires_grad or Xt.requires_grad
+        ws = SSWWorkspace.lease(dev, B, n, m, L, need_grad)
+        out = torch.empty(B + 2, dtype=torch.float32, device=dev)        # [pair_loss (B) | total (2)]
         stream = _stream_ptr(dev)
         weighted = wu is not None or wv is not None
         general = weighted or (float(p) != 1.0 and n != m)      # p == 1 with uniform weights: level-median kernel
+        cs = ws.coef_s.data_ptr() if need_grad else None
+        ct = ws.coef_t.data_ptr() if need_grad else None
         with torch.cuda.device(dev):
             if general:
                 # n != m and / or weights: the reference's bisection over the cut, followed step for step
-                coef_s = coef_t = None
-                if need_grad:
-                    coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev)
-                    coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev)
-                theta = torch.empty(B * L, dtype=torch.float32, device=dev)
 
                 def wargs(w, cnt):
                     if w is None:
@@ -96,47 +160,55 @@ class _PairLosses(torch.autograd.Function):
                 wv_p, wv_s = wargs(wv, m)
                 _lib.check(lib.shw_ssw_forward_general(
                     Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), wu_p, wv_p, wu_s, wv_s, B, n, m, L, stride,
-                    float(p), slice_cost.data_ptr(), theta.data_ptr(),
-                    coef_s.data_ptr() if need_grad else None, coef_t.data_ptr() if need_grad else None, stream),
+                    float(p), ws.slice_cost.data_ptr(), ws.slice_aux.data_ptr(), cs, ct, stream),
                     "shw_ssw_forward_general")
-                slice_shift.zero_()
-                if need_grad:
-                    ctx.save_for_backward(Xs_c, Xt_c, Us_c, coef_s, coef_t)
-                    ctx.dims = (B, n, m, L, stride)
             elif need_grad:
-                coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev)
-                coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev)
                 _lib.check(lib.shw_ssw_forward_grad(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), B, n, m, L,
-                                                    stride, float(p), slice_cost.data_ptr(), slice_shift.data_ptr(),
-                                                    coef_s.data_ptr(), coef_t.data_ptr(), stream),
+                                                    stride, float(p), ws.slice_cost.data_ptr(),
+                                                    ws.slice_aux.data_ptr(), cs, ct, stream),
                            "shw_ssw_forward_grad")
-                ctx.save_for_backward(Xs_c, Xt_c, Us_c, coef_s, coef_t)
-                ctx.dims = (B, n, m, L, stride)
             else:
                 _lib.check(lib.shw_ssw_forward(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(), B, n, m, L, stride,
-                                               float(p), slice_cost.data_ptr(), slice_shift.data_ptr(), stream),
+                                               float(p), ws.slice_cost.data_ptr(), ws.slice_aux.data_ptr(), stream),
                            "shw_ssw_forward")
-            _lib.check(lib.shw_ssw_reduce(slice_cost.data_ptr(), B, L, 1.0 / L, pair_loss.data_ptr(), None, stream),
-                       "shw_ssw_reduce")
-        cost2d, shift2d = slice_cost.view(B, L), slice_shift.view(B, L)
-        ctx.mark_non_differentiable(cost2d, shift2d)
-        return pair_loss, cost2d, shift2d
+            _lib.check(lib.shw_ssw_reduce(ws.slice_cost.data_ptr(), B, L, 1.0 / L, out.data_ptr(),
+                                          out.data_ptr() + 4 * B, stream), "shw_ssw_reduce")
+        cost2d = shift2d = None
+        if want_slices:
+            cost2d = ws.slice_cost.view(B, L).clone()
+            shift2d = torch.zeros(B, L, dtype=torch.int32, device=dev) if general else ws.slice_aux.view(B, L).clone()
+            ctx.mark_non_differentiable(cost2d, shift2d)
+        if need_grad:
+            ctx.save_for_backward(Xs_c, Xt_c, Us_c)
+            ctx.lease = _Lease(ws)                  # the coefficients stay put until this node dies
+            ctx.dims = (B, n, m, L, stride)
+            ctx.set_materialize_grads(False)
+        else:
+            ws.release()                            # stream-ordered: the next lease is on the same stream
+        return out[:B], out[B:B + 1], cost2d, shift2d
 
     @staticmethod
-    def backward(ctx, g_pair, _g_cost, _g_shift):
+    def backward(ctx, g_pair, g_total, _g_cost, _g_shift):
         lib = _lib.load()
-        Xs_c, Xt_c, Us_c, coef_s, coef_t = ctx.saved_tensors
+        Xs_c, Xt_c, Us_c = ctx.saved_tensors
+        ws = ctx.lease.ws
         B, n, m, L, stride = ctx.dims
         dev = Xs_c.device
         gxs = torch.empty_like(Xs_c)
         gxt = torch.empty_like(Xt_c)
+        if g_pair is None and g_total is None:
+            return (None,) * 9
+        # the upstream gradients go to the kernel as they are: row b is scaled by g_pair[b] + g_total[0] there
+        gp = g_pair.to(torch.float32).contiguous() if g_pair is not None else None
+        gt = g_total.to(torch.float32).contiguous() if g_total is not None else None
         with torch.cuda.device(dev):
             _lib.check(lib.shw_ssw_backward_points(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(),
-                                                   coef_s.data_ptr(), coef_t.data_ptr(), B, n, m, L, stride,
-                                                   1.0 / L, gxs.data_ptr(), gxt.data_ptr(), _stream_ptr(dev)),
+                                                   ws.coef_s.data_ptr(), ws.coef_t.data_ptr(), B, n, m, L, stride,
+                                                   1.0 / L, gp.data_ptr() if gp is not None else None,
+                                                   gt.data_ptr() if gt is not None else None, gxs.data_ptr(),
+                                                   gxt.data_ptr(), _stream_ptr(dev)),
                        "shw_ssw_backward_points")
-        w = g_pair.to(torch.float32).view(B, 1, 1)
-        return gxs * w, gxt * w, None, None, None, None, None
+        return gxs, gxt, None, None, None, None, None, None, None
 
 
 def _check_weights(name, w, count, B, dev):
@@ -149,11 +221,13 @@ def _check_weights(name, w, count, B, dev):
     return w.detach().contiguous()
 
 
-def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weights=None):
+def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weights=None, return_total=False):
     """Core op: batched clouds (B,n,3), (B,m,3); directions (B,L,3,2) or shared (L,3,2); optional weights
     (n,) / (B,n) and (m,) / (B,m).
     Returns (B,) per-pair losses = mean over slices of W_p^p on the slice circle
-    [optionally also the (B,L) per-slice costs and optimal shifts]."""
+    [optionally also the (B,L) per-slice costs and optimal shifts; or, with return_total, the shape-[1] sum over
+    pairs that the reduction kernel produces in the same launch (the batched reference value, _fast.py:291-293)].
+    Scratch (per-slice arrays, gradient coefficients) lives in a pooled SSWWorkspace; results are fresh tensors."""
     _check_cloud("Xs", Xs)
     _check_cloud("Xt", Xt)
     _check_cloud_dirs(Us)
@@ -168,7 +242,13 @@ def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weig
         raise ValueError("need at least one slice and one point per cloud")
     wu = _check_weights("u_weights", u_weights, Xs.shape[1], Xs.shape[0], Xs.device)
     wv = _check_weights("v_weights", v_weights, Xt.shape[1], Xs.shape[0], Xs.device)
-    pair, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared, wu, wv)
+    # evaluation under torch.no_grad() on inputs that still carry requires_grad must not run the
+    # training kernel / allocate the coefficient scratch
+    need_grad = torch.is_grad_enabled() and (Xs.requires_grad or Xt.requires_grad)
+    pair, total, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared, wu, wv, need_grad,
+                                                 bool(return_slices))
+    if return_total:
+        return pair, total
     if return_slices:
         return pair, cost, shift
     return pair
@@ -189,8 +269,8 @@ def sliced_cost(Xs, Xt, Us, p=2, u_weights=None, v_weights=None):
     if Xs.dim() == 2:
         pair = ssw_pair_losses(Xs.unsqueeze(0), Xt.unsqueeze(0), Us, p, u_weights=u_weights, v_weights=v_weights)
         return pair[0]
-    pair = ssw_pair_losses(Xs, Xt, Us, p, u_weights=u_weights, v_weights=v_weights)
-    return pair.sum().reshape(1)
+    _, total = ssw_pair_losses(Xs, Xt, Us, p, u_weights=u_weights, v_weights=v_weights, return_total=True)
+    return total
 
 
 def sliced_wasserstein_sphere(Xs, Xt, num_projections, device, u_weights=None, v_weights=None, p=2):

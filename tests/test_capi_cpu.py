@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol(shw):
     lib = shw._lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.shw_abi_version() == 1
+    assert lib.shw_abi_version() == 2
     assert lib.shw_max_points() == 8192
     assert lib.shw_ssw_coef_bytes(2, 10, 20, 3) == 2 * 3 * 30 * 4
 

@@ -25,11 +25,13 @@ def _free_port():
 def _oracle_local(Xs, Xt, Us, p):
     from oracle import ref_mirror
     shared = Us.dim() == 3
+    if Xs.shape[0] == 0:
+        return Xs.new_zeros(0)
     return torch.stack([ref_mirror.per_slice_costs(Xs[b], Xt[b], Us if shared else Us[b], p).mean()
                         for b in range(Xs.shape[0])])
 
 
-def _worker(rank, world, port, mode, shared, out_dir):
+def _worker(rank, world, port, mode, shared, out_dir, B=3, L=6):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,11 +40,11 @@ def _worker(rank, world, port, mode, shared, out_dir):
     import shw_amd
     from shw_amd import dist as sd
     g = torch.Generator().manual_seed(99)
-    B, n, L = 3, 64, 6
+    n = 64
     x = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=g), dim=-1).requires_grad_(True)
     y = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=g), dim=-1).requires_grad_(True)
     U = torch.linalg.qr(torch.randn(*((L,) if shared else (B, L)), 3, 2, generator=g))[0]
-    w = torch.tensor([1.0, -2.0, 0.5])
+    w = torch.tensor([1.0, -2.0, 0.5])[:B]
     pair = sd.sharded_pair_losses(x, y, U, 2, mode=mode, local_fn=_oracle_local)
     (pair * w).sum().backward()
     total = sd.sharded_sliced_cost(x.detach(), y.detach(), U, 2, mode=mode, local_fn=_oracle_local)
@@ -72,6 +74,27 @@ def test_two_rank_sharding_matches_single_process(tmp_path, mode, shared):
         assert np.allclose(r["pair"], ref.detach().numpy(), rtol=2e-6)
         assert np.allclose(r["total"], ref.detach().sum().numpy(), rtol=2e-6)
         assert np.allclose(r["own"], ref.detach().sum().numpy(), rtol=2e-6)
+        assert np.allclose(r["gx"], x.grad.numpy(), rtol=1e-4, atol=1e-9)
+        assert np.allclose(r["gy"], y.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["pairs", "slices"])
+def test_a_rank_without_work_still_joins_the_backward_collectives(tmp_path, mode):
+    """world 3 with B = 2 pairs ("pairs" mode) resp. L = 2 slices ("slices" mode): rank 2 owns nothing.  Its
+    backward must still enter the input-gradient all-reduce (it used to skip it and the other
+    ranks hung until the collective timed out); every rank ends with the full single-process gradient."""
+    world, B, L = 3, 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, False, str(tmp_path), B, L), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(99)
+    n = 64
+    x = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=g), dim=-1).requires_grad_(True)
+    y = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=g), dim=-1).requires_grad_(True)
+    U = torch.linalg.qr(torch.randn(B, L, 3, 2, generator=g))[0]
+    ref = _oracle_local(x, y, U, 2)
+    (ref * torch.tensor([1.0, -2.0])).sum().backward()
+    for rank in range(world):
+        r = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert np.allclose(r["pair"], ref.detach().numpy(), rtol=2e-6)
         assert np.allclose(r["gx"], x.grad.numpy(), rtol=1e-4, atol=1e-9)
         assert np.allclose(r["gy"], y.grad.numpy(), rtol=1e-4, atol=1e-9)
 

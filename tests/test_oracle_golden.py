@@ -194,3 +194,108 @@ def test_g7_sinkhorn_mirror(golden, eps, iters):
     assert rel(l1.sum().numpy(), g["cost_L1_sum"]) < 2e-5
     n2, _, _, _ = sinkhorn_mirror.sinkhorn_costs(T(g["x"]), T(g["y"]), 0.05, 60, cost_pow=2)
     assert rel(n2.pow(0.5).mean().numpy(), g["cost_N2_mean"]) < 2e-5
+
+
+# ---------------------------------------------------------------- G8: phi-max wrappers (host logic of the package)
+class LinearSphereMap(torch.nn.Module):
+    """phi of fixture G8 (oracle/make_golden.py): x -> normalize(x W^T + b)"""
+
+    def __init__(self, W, b):
+        super().__init__()
+        self.lin = torch.nn.Linear(3, 3)
+        with torch.no_grad():
+            self.lin.weight.copy_(torch.as_tensor(W))
+            self.lin.bias.copy_(torch.as_tensor(b))
+
+    def forward(self, x):
+        return torch.nn.functional.normalize(self.lin(x), dim=-1)
+
+
+@pytest.mark.parametrize("tag", ["pair", "fast"])
+@pytest.mark.parametrize("mode", ["train", "test"])
+def test_g8_phi_max_wrappers_host_logic_with_the_cpu_oracle_as_ssw(golden, tag, mode):
+    """The package's wrappers (modules.py) are device-agnostic host code: driven on CPU with an SSW callable that
+    evaluates the CPU oracle on the fixture's fixed directions they must retrace what the REAL wrappers
+    (max_spherical_sliced_w.py:498-536, _fast.py:346-380) did with the real sliced_cost: the per-iteration ssw
+    values the reference printed, the phi weights after max_iter Adam ascent steps, the returned value and maps."""
+    import shw_amd
+    g = golden("g8_phi_max.npz")
+    U = T(g["U_pair"] if tag == "pair" else g["U_batch"])
+    if tag == "pair":
+        cls = shw_amd.max_spherical_wassersten_distance
+        ssw = lambda a, b, L, device, p=2: ref_mirror.sliced_cost(a, b, U, p=p)           # noqa: E731
+    else:
+        cls = shw_amd.max_spherical_wassersten_distance_fast
+        ssw = lambda a, b, L, device, p=2: ref_mirror.sliced_cost_batched(a, b, U, p=p)   # noqa: E731
+    phi = LinearSphereMap(g["W0"], g["b0"])
+    opt = torch.optim.Adam(phi.parameters(), lr=float(g["lr"]))
+    crit = cls(U.shape[-3], phi, ssw, opt, p=2, max_iter=int(g["max_iter"]), device="cpu")
+    trace = []
+    crit.on_inner_value = trace.append
+    a, b = T(g["first"]).requires_grad_(True), T(g["second"]).requires_grad_(True)
+    val, fa, fb = crit(a, b, train_or_test=mode)
+    key = f"{tag}_{mode}"
+    assert rel(val.detach().numpy().reshape(-1), g[f"{key}_ssw"]) < 1e-5
+    assert len(trace) == len(g[f"{key}_trace"])
+    if trace:
+        assert rel(np.array(trace), g[f"{key}_trace"]) < 1e-5
+    assert np.abs(phi.lin.weight.detach().numpy() - g[f"{key}_W"]).max() < 1e-5
+    assert np.abs(phi.lin.bias.detach().numpy() - g[f"{key}_b"]).max() < 1e-5
+    assert np.abs(fa.detach().numpy() - g[f"{key}_phi_first"]).max() < 1e-5
+    opt.zero_grad()
+    val.sum().backward()
+    scale = np.abs(g[f"{key}_g_first"]).max()
+    assert np.abs(a.grad.numpy() - g[f"{key}_g_first"]).max() < 1e-3 * scale
+    assert np.abs(b.grad.numpy() - g[f"{key}_g_second"]).max() < 1e-3 * scale
+
+
+# ---------------------------------------------------------------- G9: the notebook's Euclidean sliced-W cell
+@pytest.mark.parametrize("tag", ["n200", "n1200"])
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("L", [1, 50])
+def test_g9_euclidean_restatement_against_the_notebook_cell(golden, tag, p, L):
+    from oracle import euclid_sw
+    g = golden("g9_notebook_esw.npz")
+    key = f"{tag}_p{p}_L{L}"
+    a = T(g[f"first_{tag}"]).requires_grad_(True)
+    val = euclid_sw.sliced_wasserstein_distance(a, T(g[f"second_{tag}"]), T(g[f"swd_theta_{key}"]), p=p)
+    val.backward()
+    assert rel(val.detach().numpy(), g[f"swd_{key}"]) < 2e-6
+    scale = np.abs(g[f"swd_gfirst_{key}"]).max()
+    assert np.abs(a.grad.numpy() - g[f"swd_gfirst_{key}"]).max() < 1e-4 * scale
+    # the directions the cell drew are what rand_projections draws from the same seed (generator parity)
+    import shw_amd
+    torch.manual_seed(int(g[f"swd_seed_{key}"]))
+    assert np.array_equal(shw_amd.rand_projections(3, L).numpy(), g[f"swd_theta_{key}"])
+
+
+# ---------------------------------------------------------------- the live trainer criterion (host logic)
+@pytest.mark.parametrize("mode", ["train", "test"])
+def test_live_criterion_mirror_against_its_restatement(golden, mode):
+    """modules.max_cos_disimilarity_wassersten_distance (mirror of s2_wasserstein.py:211-262) is host code: on CPU,
+    with a CSW built from the CPU oracle, it must retrace the statement-by-statement restatement in
+    oracle/phi_max_mirror.py (parity unpinned by fixtures: the reference module needs POT to import)."""
+    import shw_amd
+    from oracle import phi_max_mirror
+    g = golden("g8_phi_max.npz")
+    U = T(g["U_batch"])
+
+    def csw(a, b):
+        pair = torch.stack([ref_mirror.per_slice_costs(a[i], b[i], U[i], p=2).mean() for i in range(a.shape[0])])
+        return phi_max_mirror.csw_from_pair_losses(pair, 2)
+
+    results = []
+    for impl in ("mirror", "restatement"):
+        phi = LinearSphereMap(g["W0"], g["b0"])
+        opt = torch.optim.Adam(phi.parameters(), lr=0.05)
+        a, b = T(g["first"]).requires_grad_(True), T(g["second"])
+        if impl == "mirror":
+            crit = shw_amd.max_cos_disimilarity_wassersten_distance(phi, csw, "cpu", opt, max_iter=3, lam=0.1)
+            val, fa, fb = crit(a, b, train_or_test=mode)
+        else:
+            val, fa, fb, _ = phi_max_mirror.criterion_forward(phi, csw, opt, a, b, 3, 0.1, mode)
+        val.backward()
+        results.append((val.item(), phi.lin.weight.detach().clone(), fa.detach().clone(), a.grad.clone()))
+    assert results[0][0] == results[1][0]
+    for x, y in zip(results[0][1:], results[1][1:]):
+        assert torch.equal(x, y)
