@@ -7,10 +7,12 @@ import numpy as np
 RECORD = []        # (label, entries, outside strict, max err / scale) of every grad_close call of the session
 
 
-def grad_close(got, ref, strict=2e-4, loose=2e-2, frac=0.005, exact=False, max_outside=None, label=None):
+def grad_close(got, ref, strict=2e-4, loose=2e-2, frac=0.0015, exact=False, max_outside=None, label=None):
     """Gradient comparison for a piecewise-smooth loss (see the header of test_ssw_gpu.py): every entry within
-    `loose` of the largest reference entry, and at most max(frac * size, 12) entries outside `strict` of it
-    (12 entries = two swapped pairs of 3-vectors).  `exact=True`: every entry inside `strict`.
+    `loose` of the largest reference entry, and at most max(frac * size, 8) entries outside `strict` of it
+    (one swapped pair of points = 6 entries).  Round 2 measured the counts of the whole suite on MI355X
+    (gpurun_out/grad_close_counts.json: 0 for most cases, worst 32 of 24576 = 0.13 % at n = 8192) and lowered the
+    allowance from 0.5 % / 12 entries to 0.15 % / 8.  `exact=True`: every entry inside `strict`.
     `max_outside` pins the COUNT of entries outside the strict bound for a fixture case: a
     regression that breaks a fraction of the entries below the allowance is still caught.  Returns that count."""
     got = np.asarray(got, dtype=np.float64)
@@ -24,7 +26,7 @@ def grad_close(got, ref, strict=2e-4, loose=2e-2, frac=0.005, exact=False, max_o
         assert err.max() < strict * scale, (err.max(), scale)
         return outside
     assert err.max() < loose * scale, (err.max(), scale)
-    allowed = max(frac * err.size, 12)
+    allowed = max(frac * err.size, 8)
     assert outside <= allowed, (outside, err.size, err.max(), scale)
     if max_outside is not None:
         assert outside <= max_outside, f"{outside} entries outside the strict bound, pinned at <= {max_outside}"

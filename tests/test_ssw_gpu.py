@@ -13,9 +13,10 @@ Tolerances (fp32 path, north_star asks for 1e-5 relative on the loss):
                                    Two fp32 evaluations of the coordinates (torch's atan2 there, the kernel's
                                    polynomial here) order near-equal coordinates (|du| ~ 1e-7) differently in a
                                    few slices, which moves the affected entries by ~(target gap)/(n L).  So:
-                                   every entry within 2e-2 of the largest entry, and all but 0.5 % of the
-                                   entries (or 12 entries, two swapped pairs) within 2e-4 of it; cases without near-ties (small n) are held to
-                                   2e-4 everywhere.
+                                   every entry within 2e-2 of the largest entry, and all but 0.15 % of the
+                                   entries (or 8 entries) within 2e-4 of it; the fixture cases G1/G2/G4 pin the
+                                   COUNT of entries outside 2e-4 at one swapped pair (6; measured: 0, once 4);
+                                   cases without near-ties (small n) are held to 2e-4 everywhere.
 """
 import numpy as np
 import pytest
@@ -65,8 +66,8 @@ def test_g1_config1_loss_slices_grads_p2(shw, golden, deg):
     assert rel(loss.item(), g[f"loss_{deg}_p2"]) < 1e-5
     assert rel(pair[0].item(), g[f"loss_{deg}_p2"]) < 1e-5
     assert np.allclose(cost[0].cpu().numpy(), g[f"per_slice_{deg}_p2"], rtol=2e-5, atol=1e-10)
-    grad_close(x.grad.cpu().numpy(), g[f"gx_{deg}_p2"])
-    grad_close(y.grad.cpu().numpy(), g[f"gy_{deg}_p2"])
+    grad_close(x.grad.cpu().numpy(), g[f"gx_{deg}_p2"], max_outside=6)
+    grad_close(y.grad.cpu().numpy(), g[f"gy_{deg}_p2"], max_outside=6)
 
 
 @pytest.mark.parametrize("deg", [90, 135, 180])
@@ -77,8 +78,8 @@ def test_g1_config1_loss_slices_grads_p1(shw, golden, deg):
     pair.sum().backward()
     assert rel(pair[0].item(), g[f"loss_{deg}_p1"]) < 1e-5
     assert np.allclose(cost[0].cpu().numpy(), g[f"per_slice_{deg}_p1"], rtol=2e-5, atol=1e-10)
-    grad_close(x.grad.cpu().numpy(), g[f"gx_{deg}_p1"])
-    grad_close(y.grad.cpu().numpy(), g[f"gy_{deg}_p1"])
+    grad_close(x.grad.cpu().numpy(), g[f"gx_{deg}_p1"], max_outside=6)
+    grad_close(y.grad.cpu().numpy(), g[f"gy_{deg}_p1"], max_outside=6)
 
 
 # ------------------------------------------------------------------------------ golden: G2
@@ -92,8 +93,8 @@ def test_g2_batched_is_sum_over_pairs(shw, golden, p):
     assert rel(val.item(), g[f"value_p{p}"]) < 1e-5
     pair = shw.ssw_pair_losses(x.detach(), y.detach(), U, p=p)
     assert np.allclose(pair.cpu().numpy(), g[f"per_pair_p{p}"], rtol=1e-5)
-    grad_close(x.grad.cpu().numpy(), g[f"gx_p{p}"])
-    grad_close(y.grad.cpu().numpy(), g[f"gy_p{p}"])
+    grad_close(x.grad.cpu().numpy(), g[f"gx_p{p}"], max_outside=6)
+    grad_close(y.grad.cpu().numpy(), g[f"gy_p{p}"], max_outside=6)
 
 
 # ------------------------------------------------------------------------------ golden: G3 (circle level, through
@@ -147,7 +148,7 @@ def test_g4_zero_target(shw, golden, p):
     val = shw.sliced_cost(x, z, U, p=p)
     val.backward()
     assert rel(val.item(), g[f"zero_target_p{p}"]) < 1e-5
-    grad_close(x.grad.cpu().numpy(), g[f"zero_target_gx_p{p}"])
+    grad_close(x.grad.cpu().numpy(), g[f"zero_target_gx_p{p}"], max_outside=6)
 
 
 @pytest.mark.parametrize("p", [1, 2])
@@ -158,8 +159,8 @@ def test_g4_unnormalised_cube(shw, golden, p):
     pair.sum().backward()
     assert rel(pair[0].item(), g[f"cube_loss_p{p}"]) < 1e-5
     assert np.allclose(cost[0].cpu().numpy(), g[f"cube_per_slice_p{p}"], rtol=2e-5, atol=1e-10)
-    grad_close(a.grad.cpu().numpy(), g[f"cube_gx_p{p}"])
-    grad_close(b.grad.cpu().numpy(), g[f"cube_gy_p{p}"])
+    grad_close(a.grad.cpu().numpy(), g[f"cube_gx_p{p}"], max_outside=6)
+    grad_close(b.grad.cpu().numpy(), g[f"cube_gy_p{p}"], max_outside=6)
 
 
 def test_g4_unequal_sizes_p1(shw, golden):
@@ -170,8 +171,8 @@ def test_g4_unequal_sizes_p1(shw, golden):
     pair.sum().backward()
     assert rel(pair[0].item(), g["n256_m200_loss_p1"]) < 1e-5
     assert np.allclose(cost[0].cpu().numpy(), g["n256_m200_per_slice_p1"], rtol=2e-5, atol=1e-10)
-    grad_close(x.grad.cpu().numpy(), g["n256_m200_gx_p1"])
-    grad_close(y.grad.cpu().numpy(), g["n256_m200_gy_p1"])
+    grad_close(x.grad.cpu().numpy(), g["n256_m200_gx_p1"], max_outside=6)
+    grad_close(y.grad.cpu().numpy(), g["n256_m200_gy_p1"], max_outside=6)
 
 
 # ------------------------------------------------------------------------------ general solver: n != m, weights
@@ -182,8 +183,8 @@ def test_g4_unequal_sizes_p2_general_solver(shw, golden):
     pair.sum().backward()
     assert rel(pair[0].item(), g["n256_m200_loss_p2"]) < 1e-5
     assert np.allclose(cost[0].cpu().numpy(), g["n256_m200_per_slice_p2"], rtol=3e-5, atol=1e-10)
-    grad_close(x.grad.cpu().numpy(), g["n256_m200_gx_p2"])
-    grad_close(y.grad.cpu().numpy(), g["n256_m200_gy_p2"])
+    grad_close(x.grad.cpu().numpy(), g["n256_m200_gx_p2"], max_outside=6)
+    grad_close(y.grad.cpu().numpy(), g["n256_m200_gy_p2"], max_outside=6)
 
 
 def test_g4_weighted_p2_general_solver(shw, golden):
@@ -939,8 +940,8 @@ def test_weighted_level_median_against_cpu_oracle(shw, n, m):
             # p = 1 coefficients are piecewise CONSTANT (+-weight): a near-tie that is ordered differently in fp32
             # and fp64 next to the median level flips one entry by its full size, hence the wide per-entry bound;
             # all but 0.5 % of the entries must still agree to 2e-4 of the largest
-            grad_close(xs.grad[b].cpu().numpy(), xd.grad.numpy(), loose=1.0, exact=(max(n, m) <= 128))
-            grad_close(ys.grad[b].cpu().numpy(), yd.grad.numpy(), loose=1.0, exact=(max(n, m) <= 128))
+            grad_close(xs.grad[b].cpu().numpy(), xd.grad.numpy(), loose=0.2, exact=(max(n, m) <= 128))
+            grad_close(ys.grad[b].cpu().numpy(), yd.grad.numpy(), loose=0.2, exact=(max(n, m) <= 128))
     if n == m:
         un = torch.full((n,), 1.0 / n, device="cuda")
         a = shw.ssw_pair_losses(x.cuda(), y.cuda(), U.cuda(), p=1)
@@ -1097,8 +1098,8 @@ def test_p1_training_kernel_gradients_against_torch_autograd_of_the_restatement(
     ref = ref_mirror.sliced_cost(xc, yc, U, p=1)
     ref.backward()
     assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-7
-    grad_close(xs.grad.cpu().numpy(), xc.grad.numpy(), loose=1.0)
-    grad_close(ys.grad.cpu().numpy(), yc.grad.numpy(), loose=1.0)
+    grad_close(xs.grad.cpu().numpy(), xc.grad.numpy(), loose=0.1)
+    grad_close(ys.grad.cpu().numpy(), yc.grad.numpy(), loose=0.1)
     assert torch.isfinite(xs.grad).all() and torch.isfinite(ys.grad).all()
 
 
