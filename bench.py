@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X spherical sliced-Wasserstein loss.
 
-Metric (BASELINE.json): point-pairs/s = B*N*L / wall time of one loss evaluation, at N=2048, L=512,
-p=2, fp32 (BASELINE config 3: batch=64).  A "step" is one full loss evaluation of the batch
-(projection + per-slice sorts + circular OT solve + reduction to the scalar) with the clouds and
-directions already resident in HBM.
+Metric (BASELINE.json): point-pairs/s = B*N*L / wall time of one loss evaluation, p=2, fp32.  A "step" is one
+full loss evaluation of the batch (projection + per-slice sorts + circular OT solve + reduction to per-pair losses
+and the scalar) with the clouds and directions already resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU (weak scaling): the (pair x slice) axis is sharded by pairs -- every rank owns 64 pairs
-(global batch 64*N) -- and the only collective is ONE RCCL all-reduce of the scalar loss.
+  N = 1 : BASELINE config 3 -- batch=64, N=M=2048, L=512 on one MI355X (the configuration the metric is quoted on).
+  N > 1 : BASELINE config 4 -- GLOBAL batch=512, N=M=2048, L=1024, the (pair x slice) work sharded over the ranks:
+          --shard slices (default, what config 4 names): rank r evaluates L/N directions of every pair;
+          --shard pairs : rank r evaluates all 1024 directions of 512/N pairs.
+          Either way each rank reduces its slices to per-pair partial sums (scaled by 1/L_global) and the ONLY
+          collective is one RCCL all-reduce (sum) of 514 floats [512 per-pair losses | total, mean] per step.
+          Total work is fixed as N grows ("scaling": "strong").
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   "roofline":     algorithmic bytes of the dominant kernel / its measured duration vs the 8 TB/s HBM peak
-  "cpu_baseline": the CPU oracle (oracle/ref_mirror.py, kind "port") timed on a bounded sample.
+  "cpu_baseline": the CPU oracle (oracle/ref_mirror.py, kind "port") timed on a bounded sample, 1 thread and
+                  the box's CPU share, median of >= 3 runs, with the CPU model
+  "parity_rel_err": max relative difference between the GPU's per-pair losses and the CPU oracle's on the sample
+                  pairs; the process exits non-zero when it exceeds 1e-5 (a wrong-but-fast kernel prints no headline)
+Other modes (--mode train | chamfer | config5 | mirror) print their own single line; they are secondary figures.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+PARITY_TOL = 1e-5               # north_star: loss values within 1e-5 relative of the reference
 
 
 def next_pow2(v):
@@ -59,16 +69,29 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def make_inputs(B, N, L, rank, device):
-    """host-generated, seeded, unit-normalised Gaussian clouds, explicit directions."""
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def make_clouds(B, N, device, pair_lo=0, pair_hi=None):
+    """host-generated, seeded, unit-normalised Gaussian clouds (every rank generates the same global
+    batch and keeps the pairs it needs, so any GPU count sees identical data)."""
+    pair_hi = B if pair_hi is None else pair_hi
+
     def cloud(seed):
         g = torch.Generator().manual_seed(seed)
-        return torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
-    x = cloud(1234 + 10 * rank)
-    y = cloud(1235 + 10 * rank)
-    g = torch.Generator().manual_seed(4321 + 10 * rank)
-    U = torch.linalg.qr(torch.randn(B, L, 3, 2, generator=g))[0]
-    return x.to(device), y.to(device), U.contiguous().to(device)
+        return torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)[pair_lo:pair_hi].contiguous()
+    return cloud(1234).to(device), cloud(1235).to(device)
+
+
+def make_directions(shw, B, L, device, pair_lo=0, pair_hi=None, slice_lo=0, slice_hi=None):
+    """Gaussian (B,L,3,2) matrices from a seeded CPU generator; the frames of the needed block come out of the HIP
+    Householder kernel (shw_stiefel_frames: LAPACK's sign convention)."""
+    pair_hi = B if pair_hi is None else pair_hi
+    slice_hi = L if slice_hi is None else slice_hi
+    g = torch.Generator().manual_seed(4321)
+    Z = torch.randn(B, L, 3, 2, generator=g)[pair_lo:pair_hi, slice_lo:slice_hi].contiguous()
+    return shw.stiefel_frames(Z.to(device))
 
 
 def main():
@@ -76,18 +99,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="GLOBAL number of pairs (default 64 at N=1, 512 at N>1)")
     ap.add_argument("--points", type=int, default=2048)
-    ap.add_argument("--slices", type=int, default=512)
+    ap.add_argument("--slices", type=int, default=None, help="GLOBAL number of slices (default 512 at N=1, 1024 at N>1)")
     ap.add_argument("--p", type=float, default=2.0)
-    ap.add_argument("--mode", default="forward", choices=["forward", "train", "chamfer"],
-                    help="forward: loss evaluation (the headline metric); train: loss + input gradients through "
-                         "the Python mirror's autograd Function; chamfer: Chamfer baseline forward")
+    ap.add_argument("--shard", default="slices", choices=["slices", "pairs"],
+                    help="N>1: which axis of the (pair x slice) work is split over the ranks")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train", "chamfer", "config5", "mirror"],
+                    help="forward: loss evaluation through the C ABI (the headline metric); mirror: the same through "
+                         "the drop-in Python call shw.sliced_cost; train: loss + input gradients through the mirror's "
+                         "autograd Function; chamfer: Chamfer baseline forward; config5: PCRNet-shaped training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as a hipGraph instead of launching eagerly (measured on MI355X: eager "
-                         "0.352 ms/step vs replay 0.358 -- the step is one ~0.35 ms kernel plus one small one, so "
-                         "replay's fixed cost outweighs the launch it saves; kept as an option)")
+                    help="replay the step as a hipGraph instead of launching eagerly (measured: no gain, the step is "
+                         "one ~0.3 ms kernel plus one small one; kept as an option)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8)
     args = ap.parse_args()
 
@@ -113,63 +138,93 @@ def main():
     import shw_amd
     lib = shw_amd._lib.load()
     from shw_amd import _lib
+    from shw_amd.dist import shard_bounds
 
-    B, N, L, p = args.batch, args.points, args.slices, args.p
-    x, y, U = make_inputs(B, N, L, rank, device)
-    stream = torch.cuda.current_stream(device).cuda_stream
-
-    slice_cost = torch.empty(B * L, dtype=torch.float32, device=device)
-    slice_shift = torch.empty(B * L, dtype=torch.int32, device=device)
-    pair_loss = torch.empty(B, dtype=torch.float32, device=device)
-    totals = [torch.empty(2, dtype=torch.float32, device=device) for _ in range(2)]   # ring: see step()
-    total = totals[0]
+    multi = world > 1
+    B = args.batch if args.batch is not None else (512 if multi else 64)
+    L = args.slices if args.slices is not None else (1024 if multi else 512)
+    N, p = args.points, args.p
 
     if args.mode != "forward":
-        return side_modes(args, shw_amd, x, y, U, device, rank)
+        return side_modes(args, shw_amd, B, N, L, device)
 
-    def enqueue_loss(out=None):
-        """The hot path: every kernel of one loss evaluation, enqueued on torch's current HIP stream."""
-        out = total if out is None else out
+    # ---- this rank's block of the (pair x slice) work
+    pair_lo, pair_hi, slice_lo, slice_hi = 0, B, 0, L
+    if multi:
+        if args.shard == "slices":
+            slice_lo, slice_hi = shard_bounds(L, world, rank)
+        else:
+            pair_lo, pair_hi = shard_bounds(B, world, rank)
+    Bl, Ll = pair_hi - pair_lo, slice_hi - slice_lo
+    x, y = make_clouds(B, N, device, pair_lo, pair_hi)
+    U = make_directions(shw_amd, B, L, device, pair_lo, pair_hi, slice_lo, slice_hi)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    slice_cost = torch.empty(max(Bl * Ll, 1), dtype=torch.float32, device=device)
+    slice_shift = torch.empty(max(Bl * Ll, 1), dtype=torch.int32, device=device)
+    # [per-pair losses of the GLOBAL batch (B) | total, mean (2)]: the block the all-reduce sums; two-deep ring
+    outs = [torch.zeros(B + 2, dtype=torch.float32, device=device) for _ in range(2)]
+
+    def enqueue_loss(out):
+        """The hot path: every kernel of one loss evaluation of this rank's block, on torch's current HIP stream.
+        Per-pair partials are scaled by 1/L_global, so the sum over ranks is the loss itself."""
         st = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(lib.shw_ssw_forward(x.data_ptr(), y.data_ptr(), U.data_ptr(), B, N, N, L, L * 6, p,
+        if Bl * Ll == 0:
+            return
+        _lib.check(lib.shw_ssw_forward(x.data_ptr(), y.data_ptr(), U.data_ptr(), Bl, N, N, Ll, Ll * 6, p,
                                        slice_cost.data_ptr(), slice_shift.data_ptr(), st), "shw_ssw_forward")
-        _lib.check(lib.shw_ssw_reduce(slice_cost.data_ptr(), B, L, 1.0 / L, pair_loss.data_ptr(),
-                                      out.data_ptr(), st), "shw_ssw_reduce")
+        _lib.check(lib.shw_ssw_reduce(slice_cost.data_ptr(), Bl, Ll, 1.0 / L, out.data_ptr() + 4 * pair_lo,
+                                      out.data_ptr() + 4 * B, st), "shw_ssw_reduce")
+
+    # ---- roofline of the dominant kernel (ssw_forward_kernel), HIP events on the launch stream, measured BEFORE
+    #      the timed region: it also brings the GPU to its steady-state clocks, which 5 warm-up steps of 0.3 ms do not
+    reps = max(20, min(args.steps, 200))
+    for _ in range(5):
+        enqueue_loss(outs[0])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        _lib.check(lib.shw_ssw_forward(x.data_ptr(), y.data_ptr(), U.data_ptr(), Bl, N, N, Ll, Ll * 6, p,
+                                       slice_cost.data_ptr(), slice_shift.data_ptr(), stream), "shw_ssw_forward")
+    ev1.record()
+    torch.cuda.synchronize(device)
+    kernel_ms = ev0.elapsed_time(ev1) / reps
 
     graph = None
-    if args.graph:
-        # launch-bound tail (two small kernels behind a ~0.3 ms one): replay the step as a hipGraph
+    if args.graph and not multi:
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
-            enqueue_loss()
+            enqueue_loss(outs[0])
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            enqueue_loss()
+            enqueue_loss(outs[0])
 
     pending = [None, None]
     counter = [0]
 
     def step():
-        """One loss evaluation.  Multi-GPU: the scalar all-reduce (the path's only collective, RCCL over xGMI)
-        is issued asynchronously on RCCL's stream and awaited one step later, so its ~40 us of launch latency
-        overlaps the next evaluation's kernels; results land in a two-deep ring of scalars."""
+        """One loss evaluation.  Multi-GPU: the all-reduce of the 514-float block (the path's only collective, RCCL
+        over xGMI) is issued asynchronously on RCCL's stream and awaited one step later, so its launch latency
+        overlaps the next evaluation's kernels; results land in a two-deep ring."""
         if dist is None:
             if graph is not None:
                 graph.replay()
             else:
-                enqueue_loss()
-            return total[0:1]
+                enqueue_loss(outs[0])
+            return outs[0]
         slot = counter[0] & 1
         counter[0] += 1
         if pending[slot] is not None:
             pending[slot].wait()
-        enqueue_loss(totals[slot])
-        loss = totals[slot][0:1]
-        pending[slot] = dist.all_reduce(loss, async_op=True)
-        return loss
+        out = outs[slot]
+        if multi and args.shard == "pairs":
+            out.zero_()                      # foreign pairs must contribute 0 to the sum
+        enqueue_loss(out)
+        pending[slot] = dist.all_reduce(out, async_op=True)
+        return out
 
     def drain():
         for w in pending:
@@ -181,13 +236,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    print("[bench] inputs ready, warming up", file=sys.stderr, flush=True)
+    log("inputs ready (rank %d: pairs [%d,%d) slices [%d,%d)), warming up" % (rank, pair_lo, pair_hi, slice_lo, slice_hi))
     for _ in range(args.warmup):
         step()
+    if dist is not None:
+        drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        out = step()
     t_enq = time.perf_counter() - t0
     if dist is not None:
         drain()
@@ -195,18 +252,25 @@ def main():
     t_sync = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    print("[bench] enqueue %.2f ms, device done %.2f ms, after barrier %.2f ms" % (1e3 * t_enq, 1e3 * t_sync, 1e3 * elapsed),
-          file=sys.stderr, flush=True)
+    log("enqueue %.2f ms, device done %.2f ms, after barrier %.2f ms" % (1e3 * t_enq, 1e3 * t_sync, 1e3 * elapsed))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_value = float(loss.item())
+    pair_losses = out[:B].clone()
+    loss_value = float(out[B].item())                     # N > 1: sum over ranks of the partial totals
 
     ms_per_step = 1e3 * elapsed / args.steps
-    print("[bench] timed region done: %.3f ms/step" % ms_per_step, file=sys.stderr, flush=True)
-    units_per_step = world * B * N * L
-    out = {
+    log("timed region done: %.3f ms/step" % ms_per_step)
+    units_per_step = B * N * L
+    cfg_name = "BASELINE config 4" if (multi and (B, N, L) == (512, 2048, 1024)) else \
+        ("BASELINE config 3" if (B, N, L) == (64, 2048, 512) else "custom")
+    sharding = "single GPU"
+    if multi:
+        sharding = ("slices: each rank takes %d of the %d directions of every pair" % (Ll, L) if args.shard == "slices"
+                    else "pairs: each rank takes %d of the %d pairs" % (Bl, B)) + \
+            "; one RCCL all-reduce (sum) of %d floats per step" % (B + 2)
+    result = {
         "metric": "point-pairs/sec (B*N*L projected+sorted+solved) at N=%d L=%d" % (N, L),
         "value": units_per_step / (elapsed / args.steps),
         "unit": "point-pairs/s",
@@ -215,68 +279,110 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if multi else "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (unit-normalised Gaussian clouds, seeds 1234/1235; QR directions, seed 4321)",
-        "config": {"workload": "BASELINE config 3: sliced-W loss forward, batch=%d pairs/GPU, N=M=%d, L=%d, p=%g, "
-                               "independent clouds" % (B, N, L, p),
-                   "global_batch": world * B, "points": N, "slices": L, "p": p,
-                   "sharding": "pairs across ranks, one all-reduce of the scalar loss" if world > 1 else "single GPU",
-                   "launch": "hipGraph replay" if args.graph else "eager"},
+        "data": "synthetic (unit-normalised Gaussian clouds, seeds 1234/1235; Householder-QR directions of seeded "
+                "Gaussians, seed 4321)",
+        "config": {"workload": "%s: sliced-W loss forward, global batch=%d pairs, N=M=%d, L=%d, p=%g, independent "
+                               "clouds" % (cfg_name, B, N, L, p),
+                   "global_batch": B, "points": N, "slices": L, "p": p, "sharding": sharding,
+                   "launch": "hipGraph replay" if graph is not None else "eager"},
         "loss": loss_value,
     }
 
-    if True:
-        # ---- roofline of the dominant kernel (ssw_forward_kernel), HIP events on the launch stream;
-        #      per GPU (every rank measures its own launches, rank 0's figure is reported)
-        reps = max(10, min(args.steps, 200))
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(reps):
-            _lib.check(lib.shw_ssw_forward(x.data_ptr(), y.data_ptr(), U.data_ptr(), B, N, N, L, L * 6, p,
-                                           slice_cost.data_ptr(), slice_shift.data_ptr(), stream), "shw_ssw_forward")
-        ev1.record()
-        torch.cuda.synchronize(device)
-        kernel_ms = ev0.elapsed_time(ev1) / reps
-        # clouds read once + directions + per-pair loss
-        algo_bytes = 12 * B * (N + N) + 24 * B * L + 4 * B
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json: FETCH_SIZE
-        # doubled per the gfx950 correction + WRITE_SIZE); only valid for the workload it was measured on
-        traffic = os.environ.get("SHW_BENCH_TRAFFIC_BYTES")
-        if traffic is None and (B, N, L, p) == (64, 2048, 512, 2.0):
+    # clouds read once + directions + per-pair loss -- for this rank's block
+    algo_bytes = 12 * Bl * (N + N) + 24 * Bl * Ll + 4 * Bl
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE/WRITE_SIZE corrected per the
+    # guide); only valid for the workload it was measured on
+    traffic = os.environ.get("SHW_BENCH_TRAFFIC_BYTES")
+    if traffic is None and (Bl, N, Ll, p) == (64, 2048, 512, 2.0):
+        for name in ("r02_traffic.json", "r01_traffic.json"):
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
                     traffic = json.load(fh)["ssw_forward_kernel<32,4,2,true>"]["traffic_bytes"]
+                break
             except Exception:
                 traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": float(traffic) if traffic else None,
-            "kernel": "ssw_forward_kernel<32,4,2,true>" if (N, p) == (2048, 2.0) else "ssw_forward_kernel",
-            "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
-            "secondary_model": {"unit": "compare-exchanges/s", "achieved": B * L * 2 * (next_pow2(N) // 2) * stages(N) / (kernel_ms * 1e-3),
-                                "note": "two bitonic sorts of next_pow2(N) keys per slice; the VALU/LDS-crossbar price "
-                                        "list in DESIGN.md section 4 puts the bound at ~0.245 ms per launch at config 3"},
-            "note": "compulsory HBM traffic is 0.06 B/point-pair: the kernel is VALU/LDS-crossbar bound (in-register "
-                    "bitonic sort), not HBM bound; see DESIGN.md for the compare-exchange model",
-            "point_pairs_per_s_kernel_only": B * N * L / (kernel_ms * 1e-3),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(x, y, U, p, args.cpu_sample_pairs)
+    result["roofline"] = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS, "traffic": float(traffic) if traffic else None,
+        "kernel": "ssw_forward_kernel<32,4,2,true>" if (N, p) == (2048, 2.0) else "ssw_forward_kernel",
+        "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
+        "secondary_model": {"unit": "compare-exchanges/s",
+                            "achieved": Bl * Ll * 2 * (next_pow2(N) // 2) * stages(N) / (kernel_ms * 1e-3),
+                            "note": "two bitonic sorts of next_pow2(N) keys per slice; DESIGN.md section 4 prices the "
+                                    "VALU / LDS-crossbar work of one launch"},
+        "note": "compulsory HBM traffic is 0.06 B/point-pair: the kernel is VALU/LDS-crossbar bound (in-register "
+                "bitonic sort), not HBM bound; see DESIGN.md for the compare-exchange model",
+        "point_pairs_per_s_kernel_only": Bl * N * Ll / (kernel_ms * 1e-3),
+    }
+
+    rc = 0
+    if rank == 0:
+        if not multi and not args.no_cpu_baseline:
+            base = cpu_baseline(x, y, U, p, args.cpu_sample_pairs)
+            ref_pairs = base.pop("_pair_losses")
+            got = pair_losses[:len(ref_pairs)].double().cpu()
+            err = float(((got - ref_pairs).abs() / ref_pairs.abs()).max())
+            result["cpu_baseline"] = base
+            result["parity_rel_err"] = err
+            result["parity_checked"] = "per-pair losses of the first %d pairs vs oracle/ref_mirror (CPU)" % len(ref_pairs)
+        else:
+            # no full CPU baseline (N > 1, or switched off): still guard the headline with a small oracle sample --
+            # the first 8 of this rank's slices of its first pair
+            err, what = mini_parity(x, y, U, slice_cost, Ll, p)
+            result["parity_rel_err"] = err
+            result["parity_checked"] = what
+        if not (result["parity_rel_err"] <= (PARITY_TOL if "cpu_baseline" in result else 2e-5)):
+            log("PARITY FAILURE: relative error %.3e against the CPU oracle" % result["parity_rel_err"])
+            rc = 1
+        # the same evaluation through the drop-in Python call (what a reference caller gets), for the record
+        if not multi:
+            result["mirror_ms_per_step"] = time_mirror(shw_amd, x, y, U, p, device)
     if dist is not None:
         dist.barrier()
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if rc == 0:
+            print(json.dumps(result), flush=True)
+        else:
+            print(json.dumps({"error": "parity guard failed", "parity_rel_err": result["parity_rel_err"]}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return rc
 
 
-def side_modes(args, shw, x, y, U, device, rank):
-    """Secondary measurements (not the headline line): training step and Chamfer baseline, single GPU."""
-    B, N, L, p = args.batch, args.points, args.slices, args.p
+def time_mirror(shw, x, y, U, p, device, reps=50):
+    """ms per `shw.sliced_cost(x, y, U, p)` -- the reference's call shape (_fast.py:258), loss-only mode."""
+    for _ in range(10):
+        shw.sliced_cost(x, y, U, p=p)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        v = shw.sliced_cost(x, y, U, p=p)
+    torch.cuda.synchronize(device)
+    del v
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
+def mini_parity(x, y, U, slice_cost, Ll, p):
+    from oracle import ref_mirror
+    k = min(8, Ll)
+    ref = ref_mirror.per_slice_costs(x[0].cpu(), y[0].cpu(), U[0, :k].cpu(), p=p).double()
+    got = slice_cost[:k].double().cpu()
+    err = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+    return err, "per-slice costs of the first %d slices of this rank's first pair vs oracle/ref_mirror (CPU), bound 2e-5" % k
+
+
+def side_modes(args, shw, B, N, L, device):
+    """Secondary measurements (not the headline line), single GPU."""
+    p = args.p
+    if args.mode == "config5":
+        return config5_mode(args, shw, device)
+    x, y = make_clouds(B, N, device)
+    U = make_directions(shw, B, L, device)
     if args.mode == "train":
         xs = x.clone().requires_grad_(True)
         ys = y.clone().requires_grad_(True)
@@ -286,6 +392,10 @@ def side_modes(args, shw, x, y, U, device, rank):
             ys.grad = None
             shw.sliced_cost(xs, ys, U, p=p).backward()
         unit, per_step = "point-pairs/s (forward + input gradients)", B * N * L
+    elif args.mode == "mirror":
+        def step():
+            shw.sliced_cost(x, y, U, p=p)
+        unit, per_step = "point-pairs/s (forward through the drop-in Python call)", B * N * L
     else:
         def step():
             shw.chamfer_distance(x, y)
@@ -301,34 +411,87 @@ def side_modes(args, shw, x, y, U, device, rank):
     print(json.dumps({"metric": args.mode, "value": per_step / el, "unit": unit, "ms_per_step": 1e3 * el,
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
                       "config": {"workload": "B=%d N=%d L=%d p=%g" % (B, N, L, p)}}), flush=True)
+    return 0
+
+
+def config5_mode(args, shw, device):
+    """BASELINE config 5: PCRNet-shaped registration network, 8 refinement iterations, B=32, N=2048, phi-max
+    criterion with the sliced loss (L=512) in the CSW slot; forward + backward + Adam (examples/config5_train_step.py).
+    Prints the step time and how much of it the sliced-loss kernels take."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("config5_train_step", os.path.join(ROOT, "examples", "config5_train_step.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    B = args.batch or 32
+    L = args.slices or 512
+    steps = min(args.steps, 50)
+    losses, times = mod.run(batch=B, points=args.points, slices=L, steps=max(steps, 6), verbose=False, criterion="csw",
+                            phi_max_iter=1, iteration_num=8)
+    med = statistics.median(times[3:])
+    ssw = mod.ssw_share(B, args.points, L, evaluations=2)
+    print(json.dumps({"metric": "config5 training step", "value": 1.0 / med, "unit": "steps/s",
+                      "ms_per_step": 1e3 * med, "ssw_ms_per_step": 1e3 * ssw, "ssw_share": ssw / med,
+                      "torch_ms_per_step": 1e3 * (med - ssw), "n_gpus": 1, "steps": len(times), "dtype": "f32",
+                      "loss_first": losses[0], "loss_last": losses[-1],
+                      "config": {"workload": "BASELINE config 5: PCRNet-shaped regressor (emb 1024, 5 FC, 8 iterations) + "
+                                             "phi-max criterion (planar flow, 1 inner step) with SlicedSphereW in the CSW "
+                                             "slot; B=%d, N=%d, L=%d, forward+backward+Adam" % (B, args.points, L)}}),
+          flush=True)
+    return 0
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(x, y, U, p, sample_pairs):
-    """The CPU oracle (torch-CPU restatement of the reference's algorithm, oracle/ref_mirror.py) on the
-    first `sample_pairs` pairs of the same workload; used here ONLY as the timed baseline."""
+    """The CPU oracle (torch-CPU restatement of the reference's algorithm, oracle/ref_mirror.py) on a bounded sample of
+    the same workload; used here ONLY as the timed baseline and as the checker of the parity guard.
+    BASELINE.md section 3 protocol, bounded to ~20-30 s: torch threads = 1 (one pair, a quarter of the slices) and
+    = this process's CPU share (first `sample_pairs` pairs, all slices); one warm-up, median of 3 runs each."""
     from oracle import ref_mirror
-    cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except Exception:
-        pass
-    cores = max(1, min(cores, int(os.environ.get("SHW_BENCH_CPU_THREADS", "16"))))   # GPU box: 16-core share per GPU
-    torch.set_num_threads(cores)
-    print("[bench] cpu baseline on %d threads ..." % cores, file=sys.stderr, flush=True)
+        visible = os.cpu_count() or 1
+    cores = max(1, min(visible, int(os.environ.get("SHW_BENCH_CPU_THREADS", "16"))))   # GPU box: 16-core share per GPU
     xs, ys, Us = x[:sample_pairs].cpu(), y[:sample_pairs].cpu(), U[:sample_pairs].cpu()
     N, L = xs.shape[1], Us.shape[1]
-    ref_mirror.sliced_cost_batched(xs[:1], ys[:1], Us[:1], p=p)          # warm-up
-    best = float("inf")
-    val = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        val = ref_mirror.sliced_cost_batched(xs, ys, Us, p=p)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": sample_pairs * N * L / best, "unit": "point-pairs/s", "cores": cores, "kind": "port",
-            "sample": "first %d pairs of the same batch (N=%d, L=%d, p=%g), best of 2 after 1 warm-up, "
-                      "torch %d threads; %.2f s per run" % (sample_pairs, N, L, p, cores, best),
-            "loss_of_sample": float(val.item())}
+
+    def timed(fn, runs=3):
+        fn()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            val = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), val
+
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d threads (%s) ..." % (cores, cpu_model()))
+    t_all, pair_vals = timed(lambda: torch.stack([ref_mirror.per_slice_costs(xs[b], ys[b], Us[b], p=p).mean()
+                                                  for b in range(sample_pairs)]))
+    L1 = max(1, L // 4)
+    torch.set_num_threads(1)
+    log("cpu baseline on 1 thread ...")
+    t_one, _ = timed(lambda: ref_mirror.per_slice_costs(xs[0], ys[0], Us[0, :L1], p=p).mean())
+    torch.set_num_threads(cores)
+    return {"value": sample_pairs * N * L / t_all, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+            "value_allcores": sample_pairs * N * L / t_all, "value_1thread": N * L1 / t_one,
+            "cpu_model": cpu_model(), "host_threads_visible": visible,
+            "sample": "threads=%d: first %d pairs of the same batch (N=%d, L=%d, p=%g), %.2f s per run; threads=1: first "
+                      "pair, first %d slices, %.2f s per run; median of 3 after 1 warm-up each"
+                      % (cores, sample_pairs, N, L, p, t_all, L1, t_one),
+            "loss_of_sample": float(pair_vals.sum().item()),
+            "_pair_losses": pair_vals.double()}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -26,6 +26,10 @@ def main():
         xs = x.clone().requires_grad_(True)
         got = shw.dist.sharded_pair_losses(xs, y, U, 2, mode=mode)
         got.sum().backward()
+        if dist.get_world_size() == 1:
+            # one rank owns every (pair, slice): the sharded evaluation IS the single-process one, bit for bit
+            assert torch.equal(got, ref), mode
+            assert torch.equal(xs.grad, ref_x.grad), mode
         assert torch.allclose(got, ref, rtol=1e-6), mode
         assert torch.allclose(xs.grad, ref_x.grad, rtol=1e-5, atol=1e-9), mode
     tot = shw.dist.sharded_sliced_cost(x, y, U, 2)
