@@ -2,6 +2,20 @@
 #include <cstdlib>
 
 #include "ssw_common.hpp"
+#include "bin_sort.hpp"
+
+#ifndef SHW_BINSORT
+#define SHW_BINSORT 1      // 1: distribution sort through LDS (bin_sort.hpp) for >= 8 keys per lane; 0: bitonic network only
+#endif
+#ifndef SHW_FWD_MINW
+#define SHW_FWD_MINW 3     // waves per SIMD asked of the register allocator at 2048 points (bin sort)
+#endif
+#ifndef SHW_BINSORT_NB_PER_EPT
+#define SHW_BINSORT_NB_PER_EPT 32   // bins = this * keys-per-lane (32: two keys per bin on average)
+#endif
+#ifndef SHW_FWD_WAVES
+#define SHW_FWD_WAVES 1    // wavefronts per workgroup of the one-wave-per-slice kernel
+#endif
 
 namespace shw {
 
@@ -14,13 +28,23 @@ constexpr int min_waves_per_simd(int ept, int pmode) {
   return ept <= 16 ? (pmode == 2 ? 6 : 4) : (ept == 32 ? (pmode == 2 ? 5 : 3) : (ept == 64 ? 3 : 1));
 }
 
+constexpr bool forward_uses_bins(int ept) { return SHW_BINSORT != 0 && ept >= 8; }
+// LDS floats per wave: the sorted target row (64*EPT) and, with the bin sort, its 32*EPT counters in front of it
+constexpr int forward_lds_floats(int ept) { return forward_uses_bins(ept) ? (64 + SHW_BINSORT_NB_PER_EPT) * ept : 64 * ept; }
+constexpr int forward_min_waves(int ept, int pmode) {
+  // bin sort: 12 KB of LDS per wave at EPT = 32 -> 13 waves per CU: ask the register allocator for 3 per SIMD
+  return forward_uses_bins(ept) ? (ept == 32 ? SHW_FWD_MINW : (ept == 16 ? 5 : 6)) : min_waves_per_simd(ept, pmode);
+}
+
 // FULL: n == m == 64*EPT (no padding atoms): mask-free projection and the fast shift evaluation.
 template <int EPT, int WAVES, int PMODE, bool FULL>
-__global__ __launch_bounds__(WAVES * 64, min_waves_per_simd(EPT, PMODE)) void ssw_forward_kernel(SswArgs A) {
+__global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE)) void ssw_forward_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool BINS = forward_uses_bins(EPT);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* vbuf = lds + wave * (EPT * kWave);
+  float* scratch = lds + wave * forward_lds_floats(EPT);
+  float* vbuf = BINS ? scratch + SHW_BINSORT_NB_PER_EPT * EPT : scratch;       // the staging buffer of the sort becomes the target row
 
   const int vid = xcd_contiguous_id(blockIdx.x, A.num_groups);
   const int s = vid * WAVES + wave;
@@ -32,30 +56,49 @@ __global__ __launch_bounds__(WAVES * 64, min_waves_per_simd(EPT, PMODE)) void ss
 #pragma unroll
   for (int i = 0; i < 6; ++i) U[i] = Ul[i];       // (3,2) row-major: U[2*d + k]
 
-  float key[EPT];
+  float key[EPT], u[EPT];
   float sum_v = 0.f, sum_u = 0.f;
 #pragma nounroll
-  for (int which = 0; which < 2; ++which) {        // 0: target -> LDS, 1: source -> registers
-    const float* X = which == 0 ? A.xt + (long)b * A.m * 3 : A.xs + (long)b * A.n * 3;
-    const int count = which == 0 ? A.m : A.n;
-    // Opaque copy of the lane id: keeps the compiler from hoisting the ~60 lane-dependent stage
-    // constants of the sort (and the point offsets) out of this loop and holding them in VGPRs.
+  for (int which = 0; which < 2; ++which) {        // 0: source -> registers, 1: target -> LDS
+    const float* X = which == 0 ? A.xs + (long)b * A.n * 3 : A.xt + (long)b * A.m * 3;
+    const int count = which == 0 ? A.n : A.m;
+    // Opaque copy of the lane id: keeps the compiler from hoisting the lane-dependent constants of the sort (and
+    // the point offsets) out of this loop and holding them in VGPRs.
     int ln = lane;
     asm volatile("" : "+v"(ln));
+#ifdef SHW_ABL_NO_COORDS       // developer ablation: pseudo-random keys instead of load + project + atan2
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      unsigned h = (unsigned)(ln * 2654435761u) ^ (unsigned)((r + 33 * which + s) * 40503u);
+      h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+      key[r] = (float)(h >> 8) * (1.0f / 16777216.0f);
+      part += key[r];
+    }
+#else
     const float part = load_coords<EPT, FULL>(X, count, ln, U, key);
-    wave_sort<EPT>(key, ln);
+#endif
+    if constexpr (BINS) wave_sort_binned<EPT, FULL>(key, ln, count, scratch);
+    else wave_sort<EPT>(key, ln);
     if (which == 0) {
+      sum_u = wave_sum(part, lane);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) u[r] = key[r];
+    } else {
       sum_v = wave_sum(part, lane);
 #pragma unroll
       for (int r = 0; r < EPT; ++r) vbuf[r * kWave + lane] = key[r];
-    } else {
-      sum_u = wave_sum(part, lane);
     }
   }
   __builtin_amdgcn_wave_barrier();
 
   float best;
-  const int k = solve_shift<EPT, PMODE, FULL>(key, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
+#ifdef SHW_ABL_NO_SOLVE
+  best = u[0] + vbuf[lane] + sum_u - sum_v;
+  const int k = 0;
+#else
+  const int k = solve_shift<EPT, PMODE, FULL>(u, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
+#endif
   if (lane == 0) {
     A.slice_cost[s] = best / (float)A.n;
     if (A.slice_shift) A.slice_shift[s] = k;
@@ -215,7 +258,7 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
   const long groups = (total + WAVES - 1) / WAVES;
   if (groups > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)groups;
-  size_t lds = (size_t)WAVES * EPT * kWave * sizeof(float);
+  size_t lds = (size_t)WAVES * forward_lds_floats(EPT) * sizeof(float);
 #ifdef SHW_DEV_OCCUPANCY_EXPERIMENT   // developer build only: pad the LDS request to lower the waves per CU
   if (const char* extra = getenv("SHW_DEV_EXTRA_LDS")) lds += (size_t)atoi(extra);
 #endif
@@ -235,7 +278,7 @@ int dispatch_forward(SswArgs& A, hipStream_t stream) {
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT   // developer switch: compile a single size class quickly
 #ifndef SHW_DEV_FWD_WAVES
-#define SHW_DEV_FWD_WAVES (SHW_DEV_ONLY_EPT <= 32 ? 4 : (SHW_DEV_ONLY_EPT == 64 ? 2 : 1))
+#define SHW_DEV_FWD_WAVES (SHW_DEV_ONLY_EPT <= 32 ? SHW_FWD_WAVES : (SHW_DEV_ONLY_EPT == 64 ? 2 : 1))
 #endif
     case SHW_DEV_ONLY_EPT: return launch_forward<SHW_DEV_ONLY_EPT, SHW_DEV_FWD_WAVES>(A, stream);
 #else
@@ -244,7 +287,7 @@ int dispatch_forward(SswArgs& A, hipStream_t stream) {
     case 4: return launch_forward<4, 4>(A, stream);
     case 8: return launch_forward<8, 4>(A, stream);
     case 16: return launch_forward<16, 4>(A, stream);
-    case 32: return launch_forward<32, 4>(A, stream);
+    case 32: return launch_forward<32, SHW_FWD_WAVES>(A, stream);
     case 64: return launch_forward_mw<2>(A, stream);            // 2049..4096 points: two waves per slice
     case 128: return launch_forward_mw<4>(A, stream);           // 4097..8192 points: four waves per slice
 #endif

@@ -42,6 +42,9 @@ __device__ __forceinline__ float dpp_mov(float x) {
                           // busy, so moving the 13 DPP stages to ds_swizzle removes ~9 % of the VALU work.
 template <int MASK>
 __device__ __forceinline__ float lane_xor(float x, int lane) {
+#ifdef SHW_ABL_XLANE_NOSWZ      // developer ablation: no LDS crossbar traffic (results are wrong)
+  { float y = x; asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x)); return y; }
+#endif
   if constexpr (SHW_XLANE_DPP == 0 && MASK < 32) {
     return as_f(__builtin_amdgcn_ds_swizzle(as_i(x), (MASK << 10) | 0x1F));
   } else if constexpr (MASK == 1) {
@@ -163,19 +166,31 @@ __device__ __forceinline__ void xlane_merges(typename P::type (&x)[EPT], int lan
   if constexpr (C <= 6) {
     constexpr int MASK = (1 << C) - 1;
     const typename P::type bnd = P::bound((lane & (1 << (C - 1))) != 0);
+#ifdef SHW_ABL_NO_XLANE
+    if constexpr (false) {
+#else
     if constexpr (EPT == 1) {
+#endif
       x[0] = P::pick(x[0], lane_xor<MASK>(x[0], lane), bnd);
     } else {
 #pragma unroll
+#ifdef SHW_ABL_NO_XLANE
+      for (int r = 0; r < 0; ++r) {
+#else
       for (int r = 0; r < EPT / 2; ++r) {          // mirror pairs (r, EPT-1-r): two temporaries live
+#endif
         const typename P::type pa = lane_xor<MASK>(x[EPT - 1 - r], lane);
         const typename P::type pb = lane_xor<MASK>(x[r], lane);
         x[r] = P::pick(x[r], pa, bnd);
         x[EPT - 1 - r] = P::pick(x[EPT - 1 - r], pb, bnd);
       }
     }
+#ifndef SHW_ABL_NO_XLANE
     xlane_stages<P, EPT, (1 << C) / 4>(x, lane);
+#endif
+#ifndef SHW_ABL_NO_INLANE
     lane_stages<P, EPT, EPT / 2>(x);
+#endif
     xlane_merges<P, EPT, C + 1>(x, lane);
   }
 }
@@ -183,8 +198,10 @@ __device__ __forceinline__ void xlane_merges(typename P::type (&x)[EPT], int lan
 // ascending sort of the 64*EPT keys of a wave; sorted position of x[r] in lane `lane` is lane*EPT + r.
 template <int EPT>
 __device__ __forceinline__ void wave_sort(float (&x)[EPT], int lane) {
+#ifndef SHW_ABL_NO_SORT
   lane_merges<F32Keys, EPT, 2>(x);
   xlane_merges<F32Keys, EPT, 1>(x, lane);
+#endif
 }
 template <int EPT>
 __device__ __forceinline__ void wave_sort(unsigned (&x)[EPT], int lane) {

@@ -21,7 +21,7 @@ for k, v in dur.items():
     if "::" in k: print(" ", k, v[0]); continue
     print("  %-92s n=%d mean=%.0f min=%d max=%d" % (k, len(v), sum(v) / len(v), min(v), max(v)))
 print("\n# PMC counters: mean per dispatch, by kernel")
-for p in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+for p in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4", "pmc_fetch", "pmc_write"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows(p + "/**/*counter_collection.csv"):
         acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
