@@ -1,0 +1,152 @@
+// shw_ssw_coop.hip -- loss-only kernel for p != 1, W wavefronts of one workgroup per (pair, slice), sorted by the
+// cooperative distribution sort of coop_sort.hpp.  See ssw_common.hpp for the path being replaced
+// (sliced_cost, max_spherical_sliced_w.py:251-286; binary_search_circle :117-207 via the shift equivalence A8).
+//
+// Per slice: project the source (every lane EPT points), sort it (registers: sorted positions gl*EPT + r), project
+// and sort the target, lay the sorted target out in LDS as [r][64 W] (conflict-free rows for the shift evaluation),
+// then minimise the convex sequence c(k) exactly like the multi-wave kernel of shw_ssw_fwd.hip: every wave evaluates
+// c(k-1), c(k), c(k+1) on its own 64*EPT source atoms, the partial sums are added across waves in wave order through
+// LDS (all waves take identical decisions).
+#include "coop_sort.hpp"
+#include "ssw_common.hpp"
+
+namespace shw {
+
+#ifndef SHW_COOP_MINW
+#define SHW_COOP_MINW 0      // 0: let the register allocator choose
+#endif
+
+template <int EPT, int W, int PMODE, bool FULL>
+__global__ __launch_bounds__(W * 64) void ssw_forward_coop_kernel(SswArgs A) {
+  typedef Coop<EPT, W> C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* cnt = reinterpret_cast<unsigned*>(lds);
+  float* buf = lds + C::NB;
+  int* red = reinterpret_cast<int*>(lds + C::NB + C::CAP);
+  float* redf = reinterpret_cast<float*>(red) + 2 * W;        // [2 parities][W][4] partial sums, then [W][2] coordinate sums
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gl = wave * 64 + lane;
+  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);   // one workgroup per (pair, slice)
+  const int b = s / A.slices, l = s - b * A.slices;
+  const int n = A.n;
+
+  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
+  float U[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+
+  coop_zero_counters<EPT, W>(cnt, gl);
+  float u[EPT], key[EPT];
+  float part_u = 0.f, part_v = 0.f;
+#pragma nounroll
+  for (int which = 0; which < 2; ++which) {                     // 0: source -> registers, 1: target -> LDS rows
+    const float* X = (which == 0 ? A.xs : A.xt) + (long)b * n * 3;
+    int g2 = gl;
+    asm volatile("" : "+v"(g2));
+    const float part = load_coords<EPT, FULL, false, C::NCOL>(X, n, g2, U, key);
+    __syncthreads();                                            // counters zeroed (and the previous cloud's rows read)
+    coop_sort<EPT, W, FULL>(key, wave, lane, n, cnt, buf, red);
+    if (which == 0) {
+      part_u = wave_sum_uniform(part, lane);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) u[r] = key[r];
+    } else {
+      part_v = wave_sum_uniform(part, lane);
+      if constexpr (W > 1) __syncthreads();                     // every wave has read its keys back from buf
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) buf[r * C::NCOL + gl] = key[r];
+    }
+  }
+  float* sums = redf + 8 * W;
+  if (lane == 0) { sums[wave * 2] = part_u; sums[wave * 2 + 1] = part_v; }
+  __syncthreads();
+  float sum_u = 0.f, sum_v = 0.f;
+#pragma unroll
+  for (int q = 0; q < W; ++q) { sum_u += sums[q * 2]; sum_v += sums[q * 2 + 1]; }
+
+  // minimise the convex sequence c(k), |k| <= n (solve_shift with the partial sums added across waves)
+  int lo = -n, hi = n;
+  float guess = rintf(sum_u - sum_v);
+  guess = fminf(fmaxf(guess, (float)lo), (float)hi);
+  int k = __builtin_amdgcn_readfirstlane((int)guess);
+  bool lo_tight = false, hi_tight = false;
+  int step = 1;
+  float cm = 0.f, c0 = 0.f, cp = 0.f;
+  for (int it = 0; it < 64; ++it) {
+    int g2 = gl;
+    asm volatile("" : "+v"(g2));
+    float pm, p0, pp;
+    if constexpr (FULL) shift_costs3_full<EPT, PMODE, C::NCOL>(u, buf, g2, k, A.p, A.p_int, pm, p0, pp);
+    else shift_costs3<EPT, PMODE, C::NCOL>(u, buf, g2, n, k, A.p, A.p_int, pm, p0, pp);
+    if constexpr (W > 1) {
+      float* slot = redf + (it & 1) * 4 * W;                    // two parities: one barrier per evaluation
+      if (lane == 0) { slot[wave * 4] = pm; slot[wave * 4 + 1] = p0; slot[wave * 4 + 2] = pp; }
+      __syncthreads();
+      cm = c0 = cp = 0.f;
+#pragma unroll
+      for (int q = 0; q < W; ++q) { cm += slot[q * 4]; c0 += slot[q * 4 + 1]; cp += slot[q * 4 + 2]; }
+      cm = as_f(__builtin_amdgcn_readfirstlane(as_i(cm)));
+      c0 = as_f(__builtin_amdgcn_readfirstlane(as_i(c0)));
+      cp = as_f(__builtin_amdgcn_readfirstlane(as_i(cp)));
+    } else {
+      cm = pm; c0 = p0; cp = pp;
+    }
+    const bool right = (cp < c0) && (k < hi);
+    const bool left = !right && (cm < c0) && (k > lo);
+    if (!right && !left) break;
+    if (right) {
+      lo = k + 1; lo_tight = true;
+      if (hi_tight) { k = lo + ((hi - lo) >> 1); } else { k = min(k + step, hi); step <<= 1; }
+    } else {
+      hi = k - 1; hi_tight = true;
+      if (lo_tight) { k = lo + ((hi - lo) >> 1); } else { k = max(k - step, lo); step <<= 1; }
+    }
+    k = __builtin_amdgcn_readfirstlane(k);
+  }
+  if (threadIdx.x == 0) {
+    A.slice_cost[s] = c0 / (float)n;
+    if (A.slice_shift) A.slice_shift[s] = k;
+  }
+}
+
+template <int EPT, int W>
+static int launch_forward_coop(SswArgs& A, hipStream_t stream) {
+  typedef Coop<EPT, W> C;
+  const long total = (long)A.pairs * A.slices;
+  if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  A.num_groups = (int)total;
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  const bool full = (A.n == C::CAP) && (A.m == C::CAP);
+  const dim3 grid((unsigned)total), block(W * 64);
+  if (A.p_int == 2) {
+    if (full) hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 2, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 2, false>), grid, block, lds, stream, A);
+  } else {
+    if (full) hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 0, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 0, false>), grid, block, lds, stream, A);
+  }
+  return (int)hipGetLastError();
+}
+
+#ifndef SHW_COOP_EPT
+#define SHW_COOP_EPT 32     // keys per lane (measured at 2048 points: 32 / W=1: 0.267 ms, 16 / W=2: 0.288, 8 / W=4: 0.292)
+#endif
+
+// padded point count -> cooperative kernel (SHW_COOP_EPT keys per lane, W = padded / (64 * EPT) waves per slice)
+int dispatch_forward_coop(SswArgs& A, hipStream_t stream) {
+  constexpr int E = SHW_COOP_EPT;
+  const int padded = next_pow2(A.n > A.m ? A.n : A.m);
+  switch (padded / (64 * E)) {
+#ifdef SHW_DEV_ONLY_EPT      // developer switch: only the 2048-point class
+    case 2048 / (64 * E): return launch_forward_coop<E, 2048 / (64 * E)>(A, stream);
+#else
+    case 1: return launch_forward_coop<E, 1>(A, stream);
+    case 2: return launch_forward_coop<E, 2>(A, stream);
+    case 4: return launch_forward_coop<E, 4>(A, stream);
+#endif
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+}  // namespace shw

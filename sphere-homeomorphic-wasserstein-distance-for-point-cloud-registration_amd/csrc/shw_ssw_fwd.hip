@@ -274,7 +274,31 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+int dispatch_forward_coop(SswArgs& A, hipStream_t stream);       // shw_ssw_coop.hip
+
+// Which loss-only kernel serves p != 1:
+//   <= 2048 (padded) points : one wave per slice (ssw_forward_kernel: in-wave distribution sort at >= 8 keys per lane)
+//   >  2048                 : W = padded / 2048 waves per slice, cooperative distribution sort (shw_ssw_coop.hip)
+// SHW_FORWARD_KERNEL=network (diagnostic, used by the tests): the multi-wave bitonic kernel above 2048 points;
+// SHW_FORWARD_KERNEL=coop: the cooperative kernel from 2048 points on.
+static int forward_family() {
+  static const int fam = [] {
+    const char* e = getenv("SHW_FORWARD_KERNEL");
+    if (e && e[0] == 'n') return 1;       // network
+    if (e && e[0] == 'c') return 2;       // coop from 2048
+    return 0;
+  }();
+  return fam;
+}
+
 int dispatch_forward(SswArgs& A, hipStream_t stream) {
+#ifndef SHW_NO_COOP
+  {
+    const int padded = next_pow2(A.n > A.m ? A.n : A.m);
+    const int fam = forward_family();
+    if ((fam == 0 && padded > 2048) || (fam == 2 && padded >= 2048)) return dispatch_forward_coop(A, stream);
+  }
+#endif
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT   // developer switch: compile a single size class quickly
 #ifndef SHW_DEV_FWD_WAVES

@@ -271,7 +271,9 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
 // CHAINED: make the addresses of a chunk depend (through an empty asm) on the last coordinate of the chunk
 // before it.  Needed where the loads are not inside a loop: the compiler otherwise issues all 3*EPT loads up
 // front and the raw points take 96 registers (shw_ssw_p1_merge.hip).
-template <int EPT, bool FULL = false, bool CHAINED = false>
+// NCOL: lanes that share the cloud (64 for one wave; 64*W when W waves of a workgroup own a slice together, `lane`
+// then being the index among those lanes): lane owns points r*NCOL + lane.
+template <int EPT, bool FULL = false, bool CHAINED = false, int NCOL = kWave>
 __device__ __forceinline__ float load_coords(const float* __restrict__ X, int count, int lane,
                                              const float (&U)[6], float (&key)[EPT], int live_count = -1) {
   // `count` bounds the addresses (clamp), `live_count` (default: count) says how many of the 64*EPT slots are
@@ -287,13 +289,13 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int raw = (r0 + j) * kWave + lane;
+      const int raw = (r0 + j) * NCOL + lane;
       const int i = FULL ? raw : min(raw, count - 1);           // clamp: branch-free, always in bounds
       px[j] = X[3 * i]; py[j] = X[3 * i + 1]; pz[j] = X[3 * i + 2];
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int i = (r0 + j) * kWave + lane;
+      const int i = (r0 + j) * NCOL + lane;
       // fma(x, u, +0): a sum that starts from +0 like the reference's matmul accumulator (:270), so that an
       // all-zero point projects to (+0, +0) -- never -0 -- and lands on coordinate 0 (G4 fixture)
       const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
