@@ -102,7 +102,7 @@ class PlanarFlow(nn.Module):
 
     def forward(self, x):
         for u, w, b in zip(self.u, self.w, self.b):
-            x = x + u * torch.tanh(x @ w + b).unsqueeze(-1)
+            x = x + u * torch.tanh((x * w).sum(-1, keepdim=True) + b)   # (x @ w would go to a rocBLAS gemv: 0.5 ms per call)
         return x
 
 

@@ -1,6 +1,13 @@
 // shw_ssw_grad.hip -- loss + gradient-coefficient kernel for p != 1 (packed-key register sort) and
 // the coefficient -> point-gradient streaming kernel.  See ssw_common.hpp.
+#include <cstdlib>
+
+#include "bin_sort_idx.hpp"
 #include "ssw_common.hpp"
+
+#ifndef SHW_GRAD_BINSORT
+#define SHW_GRAD_BINSORT 1     // 1: distribution sort with indices (bin_sort_idx.hpp) at >= 8 keys per lane
+#endif
 
 namespace shw {
 
@@ -28,6 +35,7 @@ namespace shw {
 // ---------------------------------------------------------------------------------------------
 // waves per SIMD asked of the register allocator: what 6 B of LDS per atom allow (160 KB per CU)
 constexpr int grad_waves_per_simd(int ept) { return ept <= 16 ? 4 : (ept == 32 ? 3 : 1); }
+constexpr bool grad_uses_bins(int ept) { return SHW_GRAD_BINSORT != 0 && ept >= 8 && ept <= 32; }
 
 template <int EPT, int WAVES, int PMODE, bool FULL>
 __global__ __launch_bounds__(WAVES * 64, grad_waves_per_simd(EPT)) void ssw_forward_grad_kernel(SswArgs A) {
@@ -42,8 +50,11 @@ __global__ __launch_bounds__(WAVES * 64, grad_waves_per_simd(EPT)) void ssw_forw
   //   vidx (2 B): original indices of the sorted target
   // The SOURCE is sorted first and stays in registers (coordinates + 16-bit index pairs) while the target
   // is sorted, so that one row serves both clouds.
+  // (distribution sort: the 2-byte index row doubles as the sort's counters -- 32*EPT of them, the same 128*EPT bytes --
+  //  which are dead before the target's sorted indices are written)
   float* row = lds + wave * (ROW * 3 / 2);
   unsigned short* vidx = reinterpret_cast<unsigned short*>(row + ROW);
+  unsigned* cnt = reinterpret_cast<unsigned*>(row + ROW);
 
   const int vid = xcd_contiguous_id(blockIdx.x, A.num_groups);
   const int s = vid * WAVES + wave;
@@ -67,7 +78,9 @@ __global__ __launch_bounds__(WAVES * 64, grad_waves_per_simd(EPT)) void ssw_forw
     asm volatile("" : "+v"(ln));
     float val[EPT];
     int idx[EPT];
-    const float part = sorted_with_indices<EPT>(X, count, ln, U, row, val, idx);
+    float part;
+    if constexpr (grad_uses_bins(EPT)) part = sorted_with_indices_binned<EPT>(X, count, ln, U, cnt, row, val, idx);
+    else part = sorted_with_indices<EPT>(X, count, ln, U, row, val, idx);
     const float total = wave_sum(part, lane);
     if (which == 0) {
       sum_u = total;
@@ -236,7 +249,17 @@ static int launch_forward_grad(SswArgs& A, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// SHW_GRAD_KERNEL=onewave (diagnostic, used by the tests): the one-wave kernel of this file at every size
+static bool grad_one_wave_forced() {
+  static const bool forced = [] { const char* e = getenv("SHW_GRAD_KERNEL"); return e && e[0] == 'o'; }();
+  return forced;
+}
+
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream) {
+  {
+    const int ept = ept_for(A.n, A.m);
+    if (ept >= 8 && ept <= 32 && !grad_one_wave_forced()) return dispatch_forward_grad2(A, stream);   // shw_ssw_grad2.hip
+  }
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT
     case SHW_DEV_ONLY_EPT: return launch_forward_grad<SHW_DEV_ONLY_EPT, 1>(A, stream);

@@ -142,17 +142,20 @@ __device__ __forceinline__ float target_unrolled(const float* vbuf, int q, int n
 // fetched 8 positions at a time to bound the registers in flight.
 // `lane` is the index of the lane among the NCOL lanes that hold the slice (wave * 64 + lane in the multi-wave
 // kernel, whose waves then add their partial sums).
-template <int EPT, int PMODE, int NCOL = 64>
-__device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float* vbuf, int lane, int n,
-                                             int k, float p, int p_int, float& cm, float& c0, float& cp) {
+// NR / r_base: the evaluation may cover only registers [r_base, r_base + NR) of every lane's EPT sorted positions
+// (u then holds those NR atoms): the two-wave training kernel gives each wave half of the source.
+template <int EPT, int PMODE, int NCOL = 64, int NR = EPT>
+__device__ __forceinline__ void shift_costs3(const float (&u)[NR], const float* vbuf, int lane, int n,
+                                             int k, float p, int p_int, float& cm, float& c0, float& cp,
+                                             int r_base = 0) {
   float sm = 0.f, s0 = 0.f, sp = 0.f;
-  const int e0 = lane * EPT;
+  const int e0 = lane * EPT + r_base;
   const int last = n - 1;
   float prev = target_unrolled<EPT, NCOL>(vbuf, min(e0, last) + k - 1, n);
   float cur = target_unrolled<EPT, NCOL>(vbuf, min(e0, last) + k, n);
-  constexpr int CH = EPT < 8 ? EPT : 8;
+  constexpr int CH = NR < 8 ? NR : 8;
 #pragma unroll
-  for (int r0 = 0; r0 < EPT; r0 += CH) {
+  for (int r0 = 0; r0 < NR; r0 += CH) {
     float nxt[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) nxt[j] = target_unrolled<EPT, NCOL>(vbuf, min(e0 + r0 + j, last) + k + 1, n);
@@ -180,11 +183,12 @@ __device__ __forceinline__ void shift_costs3(const float (&u)[EPT], const float*
 // position (l + kh + c)*EPT + row with  row = (kl + j) mod EPT  and carry  c = (kl + j) div EPT in
 // {0,1,2}: row and c are WAVE-UNIFORM, so each fetch is  ds_read(addr_c + row*256) + turn_c  with the
 // three per-lane (address, turn) pairs prepared once per evaluation -- 4 VALU per fetch instead of ~15.
-template <int EPT, int PMODE, int NCOL = 64>
-__device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const float* vbuf, int lane, int k,
-                                                  float p, int p_int, float& cm, float& c0, float& cp) {
+template <int EPT, int PMODE, int NCOL = 64, int NR = EPT>
+__device__ __forceinline__ void shift_costs3_full(const float (&u)[NR], const float* vbuf, int lane, int k,
+                                                  float p, int p_int, float& cm, float& c0, float& cp,
+                                                  int r_base = 0) {
   constexpr int LOG = __builtin_ctz(EPT);
-  const int base = k - 1;
+  const int base = k - 1 + r_base;            // registers [r_base, r_base + NR): the same window, r_base further on
   const int kl = base & (EPT - 1);
   const int kh = base >> LOG;                                   // floor division (arithmetic shift)
   int addr[3];
@@ -206,9 +210,9 @@ __device__ __forceinline__ void shift_costs3_full(const float (&u)[EPT], const f
   };
   float sm = 0.f, s0 = 0.f, sp = 0.f;
   float prev = fetch(0), cur = fetch(1);
-  constexpr int CH = EPT < 8 ? EPT : 8;
+  constexpr int CH = NR < 8 ? NR : 8;
 #pragma unroll
-  for (int r0 = 0; r0 < EPT; r0 += CH) {
+  for (int r0 = 0; r0 < NR; r0 += CH) {
     float nxt[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) nxt[j] = fetch(r0 + j + 2);
@@ -338,8 +342,9 @@ __device__ __forceinline__ bool pair_after(float va, int ia, float vb, int ib) {
 // Put a nearly sorted (val, idx) sequence -- sorted position lane*EPT + r -- into exact stable order.
 // One round = exchange of pairs (2j, 2j+1) then (2j+1, 2j+2); rounds repeat until a round is clean.
 template <int EPT>
-__device__ __forceinline__ void exact_order_fixup(float (&val)[EPT], int (&idx)[EPT], int lane) {
-  for (int round = 0; round < EPT * kWave; ++round) {       // bound: odd-even transposition sorts in n rounds
+__device__ __forceinline__ void exact_order_fixup(float (&val)[EPT], int (&idx)[EPT], int lane,
+                                                  int max_rounds = EPT * kWave) {
+  for (int round = 0; round < max_rounds; ++round) {        // bound: odd-even transposition sorts in n rounds
     bool any = false;
     auto exch = [&](float& va, int& ia, float& vb, int& ib) {
       const bool sw = pair_after(va, ia, vb, ib);
@@ -378,6 +383,53 @@ __device__ __forceinline__ void exact_order_fixup(float (&val)[EPT], int (&idx)[
   }
 }
 
+// From the sorted packed words to (exact coordinate, original index) in exact stable order: gather the fp32
+// coordinates by index from `orig` (coordinates by ORIGINAL index, pads +inf) and repair the order of atoms whose
+// quantised coordinates collide.  Shared by the network sort (sorted_with_indices) and the distribution sort
+// (bin_sort_idx.hpp).
+// FULL: count == 64*EPT (no pads): the pad tests fold away.
+template <int EPT, bool FULL = false>
+__device__ __forceinline__ void unpack_sorted_words(const unsigned (&pk)[EPT], const float* orig, int count, int lane,
+                                                    float (&val)[EPT], int (&idx)[EPT]) {
+  typedef Packing<EPT> PK;
+  // A pad is recognised by its index field (all ones, >= count whenever pads exist), NOT by the key value:
+  // the real atom with index 64*EPT-1 and a coordinate in the top quantisation cell packs to the same word
+  // 0xffffffff when the row is full.
+  // Equal quantised coordinate on adjacent atoms?  (`chain`: on three in a row -- only then can one repair round be
+  // not enough.)
+  bool collide = false, chain = false;
+  bool prev_eq;
+  {
+    const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)pk[0]);
+    const unsigned prv = (unsigned)__builtin_amdgcn_ds_bpermute(max(lane - 1, 0) << 2, (int)pk[EPT - 1]);
+    collide = (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) &&
+              (FULL || (int)(pk[EPT - 1] & PK::IDX_MASK) < count);
+    prev_eq = (lane > 0) && (((pk[0] ^ prv) >> PK::IDX_BITS) == 0) && (FULL || (int)(pk[0] & PK::IDX_MASK) < count);
+  }
+#pragma unroll
+  for (int r = 1; r < EPT; ++r) {
+    const bool eq = (((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0) && (FULL || (int)(pk[r] & PK::IDX_MASK) < count);
+    chain |= eq && prev_eq;
+    collide |= eq;
+    prev_eq = eq;
+  }
+  // (the packed words are dead from here on: index and gathered coordinate take their registers)
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    idx[r] = (int)(pk[r] & PK::IDX_MASK);
+    val[r] = (!FULL && idx[r] >= count) ? __builtin_inff() : orig[FULL ? idx[r] : min(idx[r], count - 1)];
+  }
+#ifndef SHW_ABL_NO_EXACTFIX
+  if (__builtin_amdgcn_readfirstlane((int)(__ballot(collide) != 0ull)) != 0) {
+    // one round repairs every colliding PAIR (ties inside a pair are already in index order: the packed order); longer
+    // chains of equal quantised coordinates (rare) get the loop-until-clean form
+    const bool chained = __builtin_amdgcn_readfirstlane((int)(__ballot(chain) != 0ull)) != 0;
+    exact_order_fixup<EPT>(val, idx, lane, chained ? EPT * kWave : 1);
+  }
+#endif
+  __builtin_amdgcn_wave_barrier();
+}
+
 // project one cloud, sort it (packed keys), recover exact sorted coordinates + original indices
 template <int EPT>
 __device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X, int count, int lane,
@@ -401,26 +453,7 @@ __device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X
   }
   wave_sort<EPT>(pk, lane);
   __builtin_amdgcn_wave_barrier();
-  // A pad is recognised by its index field (all ones, >= count whenever pads exist), NOT by the key value:
-  // the real atom with index 64*EPT-1 and a coordinate in the top quantisation cell packs to the same word
-  // 0xffffffff when the row is full.
-  bool collide = false;                                  // equal quantised coordinate on adjacent atoms?
-  {
-    const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)pk[0]);
-    collide = (lane < 63) && (((pk[EPT - 1] ^ nxt) >> PK::IDX_BITS) == 0) &&
-              ((int)(pk[EPT - 1] & PK::IDX_MASK) < count);
-  }
-#pragma unroll
-  for (int r = 1; r < EPT; ++r)
-    collide |= (((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0) && ((int)(pk[r] & PK::IDX_MASK) < count);
-  // (the packed words are dead from here on: index and gathered coordinate take their registers)
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) {
-    idx[r] = (int)(pk[r] & PK::IDX_MASK);
-    val[r] = (idx[r] >= count) ? __builtin_inff() : orig[idx[r]];
-  }
-  if (__builtin_amdgcn_readfirstlane((int)(__ballot(collide) != 0ull)) != 0) exact_order_fixup<EPT>(val, idx, lane);
-  __builtin_amdgcn_wave_barrier();
+  unpack_sorted_words<EPT>(pk, orig, count, lane, val, idx);
   return part;
 }
 
@@ -448,6 +481,7 @@ inline int ept_for(int n, int m) {
 // dispatchers, one per translation unit (SswArgs validated by the C entry points in shw_capi.hip)
 int dispatch_forward(SswArgs& A, hipStream_t stream);        // shw_ssw_fwd.hip   p != 1, loss only
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream);   // shw_ssw_grad.hip  p != 1, loss + coefficients
+int dispatch_forward_grad2(SswArgs& A, hipStream_t stream);  // shw_ssw_grad2.hip two waves per slice, 257..2048 points
 int dispatch_level_median(SswArgs& A, hipStream_t stream);   // shw_ssw_p1.hip    p == 1 (coef_s != NULL: + coefficients)
 int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                      float* slice_theta, hipStream_t stream);   // shw_ssw_general.hip  p != 1, n != m / weights

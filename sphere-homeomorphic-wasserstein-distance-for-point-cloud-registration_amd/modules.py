@@ -85,11 +85,94 @@ class max_spherical_wassersten_distance(nn.Module):
         return self._ssw(first_t, second_t), first_t, second_t
 
 
+class GraphedAscent:
+    """hipGraph capture of ONE inner iteration of a phi-max loop -- phi forward on both (detached) clouds, the sliced
+    loss forward + gradient kernels, phi backward, optimizer step -- replayed `max_iter` times per trainer step
+    (the loop of _fast.py:359-372).  An inner iteration is ~40 small launches around three HIP
+    kernels; replaying it removes the launch and Python overhead that dominates once the loss kernel is fast.
+
+    Requirements of graph capture: static input buffers (the clouds are copied into them, two B*N*3 copies per
+    trainer step) and an optimizer whose step is capturable (torch.optim.Adam(..., capturable=True)).  Directions
+    drawn inside the loss (torch.randn on the device generator) stay random across replays: torch registers the
+    generator with the graph.  The first call of a shape runs `warmup` eager iterations on a side stream (they
+    count as iterations of the loop) and captures; every later iteration is a replay.  Replays execute the same
+    kernels on the same buffers as the eager loop: results are bit-identical (tests/test_r2_gpu.py)."""
+
+    def __init__(self, phi, phi_op, objective, warmup=2):
+        self.phi, self.phi_op, self.objective, self.warmup = phi, phi_op, objective, warmup
+        self._graphs = {}
+
+    def _iteration(self, a, b):
+        value = self.objective(self.phi(a), self.phi(b))
+        self.phi_op.zero_grad(set_to_none=True)
+        (-value).sum().backward()
+        self.phi_op.step()
+        return value.detach()
+
+    def run(self, first, second, iters, observer=None):
+        if iters <= 0:
+            return
+        if not first.is_cuda:
+            raise RuntimeError("GraphedAscent needs device tensors")
+        for group in self.phi_op.param_groups:
+            if not group.get("capturable", False):
+                raise RuntimeError("the phi optimizer must be created with capturable=True to be replayed in a hipGraph")
+        key = (tuple(first.shape), tuple(second.shape), first.dtype, first.device)
+        entry = self._graphs.get(key)
+        done = 0
+        if entry is None:
+            a, b = first.detach().clone(), second.detach().clone()
+            side = torch.cuda.Stream(first.device)
+            side.wait_stream(torch.cuda.current_stream(first.device))
+            with torch.cuda.stream(side):
+                while done < min(self.warmup, iters):
+                    v = self._iteration(a, b)
+                    done += 1
+                    if observer is not None:
+                        observer(float(v.sum()))
+            torch.cuda.current_stream(first.device).wait_stream(side)
+            if done == iters:
+                return                      # nothing left to replay this time: capture on the next call
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                value = self._iteration(a, b)
+            entry = (graph, a, b, value)
+            self._graphs[key] = entry
+        graph, a, b, value = entry
+        a.copy_(first.detach())
+        b.copy_(second.detach())
+        while done < iters:
+            graph.replay()
+            done += 1
+            if observer is not None:
+                observer(float(value.sum()))
+
+
 class max_spherical_wassersten_distance_fast(max_spherical_wassersten_distance):
-    """phi-max wrapper, batched SSW (_fast.py:346-380)."""
+    """phi-max wrapper, batched SSW (_fast.py:346-380).  `graph=True`: the inner ascent iterations are captured once
+    per input shape and replayed (GraphedAscent); the returned value and maps are computed eagerly as in the
+    reference, so the trainer's backward through them is unchanged."""
+
+    def __init__(self, num_projections, phi, SSW, phi_op, p=2, max_iter=10, device="cuda", verbose=False, graph=False):
+        super().__init__(num_projections, phi, SSW, phi_op, p=p, max_iter=max_iter, device=device, verbose=verbose)
+        self._graphed = GraphedAscent(phi, phi_op, self._ssw) if graph else None
 
     def _ssw(self, a, b):
         return self.SSW(a, b, self.num_projections, self.device, p=self.p)
+
+    def forward(self, first_samples, second_samples, train_or_test="train"):
+        if self._graphed is None or train_or_test != "train":
+            return super().forward(first_samples, second_samples, train_or_test)
+        observer = None
+        if self.verbose or self.on_inner_value is not None:
+            def observer(v):
+                if self.verbose:
+                    print(v)
+                if self.on_inner_value is not None:
+                    self.on_inner_value(v)
+        self._graphed.run(first_samples, second_samples, self.max_iter, observer)
+        first_t, second_t = self.phi(first_samples), self.phi(second_samples)
+        return self._ssw(first_t, second_t), first_t, second_t
 
 
 class max_cos_disimilarity_wassersten_distance(nn.Module):
@@ -99,10 +182,12 @@ class max_cos_disimilarity_wassersten_distance(nn.Module):
     the drop-in passes `SlicedSphereW`.  The s2_wasserstein module itself cannot be imported without POT, so this
     mirror is checked against a restatement (oracle/phi_max_mirror.py): parity unpinned by fixtures."""
 
-    def __init__(self, phi, CSW, device, phi_op, max_iter=10, lam=0.1, psi_minibatch_size=5):
+    def __init__(self, phi, CSW, device, phi_op, max_iter=10, lam=0.1, psi_minibatch_size=5, graph=False):
         super().__init__()
         self.phi, self.CSW, self.phi_op = phi, CSW, phi_op
         self.max_iter, self.device, self.reg_lam = max_iter, device, lam
+        # graph=True: the inner iterations are replayed from a hipGraph (GraphedAscent); needs a capturable optimizer
+        self._graphed = GraphedAscent(phi, phi_op, self._ascent_objective) if graph else None
 
     @staticmethod
     def regularization_of_normalizing_flow(x):
@@ -110,19 +195,24 @@ class max_cos_disimilarity_wassersten_distance(nn.Module):
             x = x.unsqueeze(0)
         return torch.sum(torch.abs(torch.linalg.vector_norm(x, dim=-1) - 1))           # :222-230
 
+    def _ascent_objective(self, a, b):
+        reg = self.reg_lam * (self.regularization_of_normalizing_flow(a) / (a.shape[0] * a.shape[1])
+                              + self.regularization_of_normalizing_flow(b) / (b.shape[0] * b.shape[1]))
+        return self.CSW(a, b) - reg                                                  # maximised (:249: loss = reg - cswd)
+
     def forward(self, first_samples, second_samples, train_or_test="train"):
         first_detach, second_detach = first_samples.detach(), second_samples.detach()
         if train_or_test == "train":
             self.phi.train()
-            for _ in range(self.max_iter):
-                self.phi_op.zero_grad()
-                a, b = self.phi(first_detach), self.phi(second_detach)
-                cswd = self.CSW(a, b)
-                reg = self.reg_lam * (self.regularization_of_normalizing_flow(a) / (a.shape[0] * a.shape[1])
-                                      + self.regularization_of_normalizing_flow(b) / (b.shape[0] * b.shape[1]))
-                loss = reg - cswd                                                    # gradient ascent (:249)
-                loss.backward(retain_graph=True)
-                self.phi_op.step()
+            if self._graphed is not None:
+                self._graphed.run(first_detach, second_detach, self.max_iter)
+            else:
+                for _ in range(self.max_iter):
+                    self.phi_op.zero_grad()
+                    a, b = self.phi(first_detach), self.phi(second_detach)
+                    loss = -self._ascent_objective(a, b)                              # gradient ascent (:249)
+                    loss.backward(retain_graph=True)
+                    self.phi_op.step()
         elif train_or_test == "test":
             self.phi.eval()
         else:
@@ -154,6 +244,6 @@ class ChamferCriterion(nn.Module):
         return chamfer_distance(template, source, batch_reduction=batch_reduction)
 
 
-__all__ = ["SlicedSphereW", "max_spherical_wassersten_distance", "max_spherical_wassersten_distance_fast",
+__all__ = ["GraphedAscent", "SlicedSphereW", "max_spherical_wassersten_distance", "max_spherical_wassersten_distance_fast",
            "max_cos_disimilarity_wassersten_distance",
            "SSWCriterion", "ChamferCriterion", "sliced_wasserstein_sphere", "sliced_wasserstein_sphere_fast"]

@@ -398,3 +398,48 @@ def test_config4_decomposition_on_one_gpu(shw):
     by_pairs = torch.cat([shw.ssw_pair_losses(x[lo:hi], y[lo:hi], U[lo:hi], p=2)
                           for lo, hi in (shw.dist.shard_bounds(B, world, r) for r in range(world))])
     assert torch.equal(by_pairs, full)
+
+
+# ------------------------------------------------------------------------------------------- phi-max fusion (8f rank 2)
+@pytest.mark.parametrize("which", ["ssw_fast", "live_criterion"])
+def test_graphed_phi_max_loop_equals_the_eager_loop_bit_for_bit(shw, golden, which):
+    """GraphedAscent: one inner iteration (phi forward, loss forward + gradient kernels, phi backward, Adam step)
+    captured into a hipGraph and replayed.  Same kernels on the same values as the eager loop: after two trainer-level
+    calls (the first warms up, captures and replays; the second only replays) the phi weights, the returned value
+    and the gradient that flows back to the clouds must be IDENTICAL to the eager wrapper's."""
+    g = golden("g8_phi_max.npz")
+    U = dev(g["U_batch"])
+    first, second = dev(g["first"]), dev(g["second"])
+    results = []
+    for graph in (False, True):
+        phi = LinearSphereMap(g["W0"], g["b0"]).cuda()
+        opt = torch.optim.Adam(phi.parameters(), lr=0.05, capturable=True)
+        if which == "ssw_fast":
+            ssw = lambda a, b, L, device, p=2: shw.sliced_cost(a, b, U, p=p)                 # noqa: E731
+            crit = shw.max_spherical_wassersten_distance_fast(16, phi, ssw, opt, p=2, max_iter=5, device="cuda",
+                                                              graph=graph)
+        else:
+            csw = lambda a, b: shw.ssw_pair_losses(a, b, U, 2).sqrt().mean()                 # noqa: E731
+            crit = shw.max_cos_disimilarity_wassersten_distance(phi, csw, "cuda", opt, max_iter=5, lam=0.1, graph=graph)
+        out = []
+        for call in range(2):
+            a = first.clone().requires_grad_(True)
+            val, fa, _ = crit(a, second, train_or_test="train")
+            val.sum().backward()
+            out.append((val.detach().clone(), phi.lin.weight.detach().clone(), phi.lin.bias.detach().clone(),
+                        fa.detach().clone(), a.grad.clone()))
+            opt.zero_grad(set_to_none=True)
+        results.append(out)
+    for call in range(2):
+        for x, y in zip(results[0][call], results[1][call]):
+            assert torch.equal(x, y), (which, call)
+
+
+def test_graphed_ascent_refuses_an_optimizer_that_cannot_be_captured(shw, golden):
+    g = golden("g8_phi_max.npz")
+    phi = LinearSphereMap(g["W0"], g["b0"]).cuda()
+    opt = torch.optim.Adam(phi.parameters(), lr=0.05)                   # capturable=False
+    crit = shw.max_spherical_wassersten_distance_fast(16, phi, shw.sliced_wasserstein_sphere_fast, opt, max_iter=2,
+                                                      device="cuda", graph=True)
+    with pytest.raises(RuntimeError, match="capturable"):
+        crit(dev(g["first"]), dev(g["second"]), train_or_test="train")
