@@ -86,12 +86,14 @@ __device__ __forceinline__ int binsort_histogram(const float (&key)[EPT], unsign
       // v_cvt_u32_f32 saturates (NaN -> 0, +inf -> 0xffffffff): the bin is always inside [0, NB)
       const unsigned t = (unsigned)(key[r0 + j] * (float)NB);
       b[j] = t < (unsigned)(NB - 1) ? t : (unsigned)(NB - 1);
+      // pads (they add 0) go to 64 different counters: 64 atomics on ONE address would be served one after the other
+      if constexpr (!FULL) b[j] = ((r0 + j) * kWave + lane < n) ? b[j] : (unsigned)lane;
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const bool live = FULL || ((r0 + j) * kWave + lane < n);
-      rank[j] = 0;
-      if (live) rank[j] = __hip_atomic_fetch_add(cnt + b[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      // pads add 0: no divergent branch around the atomic
+      const unsigned inc = (FULL || ((r0 + j) * kWave + lane < n)) ? 1u : 0u;
+      rank[j] = __hip_atomic_fetch_add(cnt + b[j], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) w[r0 + j] = (rank[j] << 16) | b[j];
@@ -155,9 +157,10 @@ __device__ __forceinline__ void binsort_place(float (&key)[EPT], const unsigned 
     for (int j = 0; j < CH; ++j) start[j] = cnt[w[r0 + j] & 0xffffu];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const bool live = FULL || ((r0 + j) * kWave + lane < n);
-      const unsigned pos = start[j] + (w[r0 + j] >> 16);
-      if (live) *reinterpret_cast<float*>(bytes + binsort_addr<EPT>(pos)) = key[r0 + j];
+      // a pad (key +inf, original index i >= n) goes to position i: the positions behind the n live keys, each once
+      const unsigned i = (unsigned)((r0 + j) * kWave + lane);
+      const unsigned pos = (FULL || (int)i < n) ? start[j] + (w[r0 + j] >> 16) : i;
+      *reinterpret_cast<float*>(bytes + binsort_addr<EPT>(pos)) = key[r0 + j];
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -167,10 +170,6 @@ __device__ __forceinline__ void binsort_place(float (&key)[EPT], const unsigned 
     const unsigned pos0 = (unsigned)lane * EPT + 4u * j;          // logical chunk j of row `lane`
     const f32x4 v = *reinterpret_cast<const f32x4*>(bytes + binsort_addr<EPT>(pos0));
     key[4 * j] = v.x; key[4 * j + 1] = v.y; key[4 * j + 2] = v.z; key[4 * j + 3] = v.w;
-  }
-  if constexpr (!FULL) {
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) key[r] = (lane * EPT + r < n) ? key[r] : __builtin_inff();
   }
   // odd-even transposition, g phases (wave-uniform trip count)
   for (int phase = 0; phase < g; phase += 2) {

@@ -59,9 +59,10 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
     unsigned rank[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      rank[j] = 0;
-      if (FULL || (r0 + j) * kWave + lane < count)
-        rank[j] = __hip_atomic_fetch_add(cnt + (pk[r0 + j] >> BIN_SHIFT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      // pads add 0 (no divergent branch), each lane to its own counter (64 atomics on one address would serialise)
+      const bool live = FULL || (r0 + j) * kWave + lane < count;
+      const unsigned bin = live ? (pk[r0 + j] >> BIN_SHIFT) : (unsigned)lane;
+      rank[j] = __hip_atomic_fetch_add(cnt + bin, live ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) rk[(r0 + j) / 4] |= (rank[j] & 0xffu) << (8 * ((r0 + j) & 3));
@@ -111,8 +112,10 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
       for (int j = 0; j < CH; ++j) start[j] = cnt[pk[r0 + j] >> BIN_SHIFT];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        const unsigned pos = start[j] + ((rk[(r0 + j) / 4] >> (8 * ((r0 + j) & 3))) & 0xffu);
-        if (FULL || (r0 + j) * kWave + lane < count) *reinterpret_cast<unsigned*>(bytes + binsort_addr<EPT>(pos)) = pk[r0 + j];
+        // a pad (word 0xffffffff, original index i >= count) goes to position i: behind the live words, each once
+        const unsigned i = (unsigned)((r0 + j) * kWave + lane);
+        const unsigned pos = (FULL || (int)i < count) ? start[j] + ((rk[(r0 + j) / 4] >> (8 * ((r0 + j) & 3))) & 0xffu) : i;
+        *reinterpret_cast<unsigned*>(bytes + binsort_addr<EPT>(pos)) = pk[r0 + j];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -121,10 +124,6 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
     for (int j = 0; j < EPT / 4; ++j) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(bytes + binsort_addr<EPT>((unsigned)lane * EPT + 4u * j));
       pk[4 * j] = v.x; pk[4 * j + 1] = v.y; pk[4 * j + 2] = v.z; pk[4 * j + 3] = v.w;
-    }
-    if constexpr (!FULL) {
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) pk[r] = (lane * EPT + r < count) ? pk[r] : 0xffffffffu;
     }
     __builtin_amdgcn_wave_barrier();
     // the buffer is free again: exact coordinates by ORIGINAL index (LDS operations of a wave execute in order)

@@ -102,12 +102,13 @@ __device__ __forceinline__ void coop_sort(float (&key)[EPT], int wave, int lane,
     for (int r = 0; r < EPT; ++r) {
       const unsigned t = (unsigned)(key[r] * (float)C::NB);          // saturating convert: NaN -> 0, +inf -> max
       b[r] = t < (unsigned)(C::NB - 1) ? t : (unsigned)(C::NB - 1);
+      // pads (they add 0) go to different counters: atomics on ONE address would be served one after the other
+      if constexpr (!FULL) b[r] = (r * C::NCOL + gl < n) ? b[r] : (unsigned)gl;
     }
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
-      const bool live = FULL || (r * C::NCOL + gl < n);
-      rank[r] = 0;
-      if (live) rank[r] = __hip_atomic_fetch_add(cnt + b[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned inc = (FULL || (r * C::NCOL + gl < n)) ? 1u : 0u;       // pads add 0: no divergent branch
+      rank[r] = __hip_atomic_fetch_add(cnt + b[r], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #pragma unroll
     for (int r = 0; r < EPT; ++r) w[r] = (rank[r] << 16) | b[r];
@@ -165,9 +166,10 @@ __device__ __forceinline__ void coop_sort(float (&key)[EPT], int wave, int lane,
     for (int r = 0; r < EPT; ++r) start[r] = cnt[w[r] & 0xffffu];
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
-      const bool live = FULL || (r * C::NCOL + gl < n);
-      const unsigned pos = start[r] + (w[r] >> 16);
-      if (live) *reinterpret_cast<float*>(bytes + coop_addr<EPT>(pos)) = key[r];
+      // a pad (key +inf, original index i >= n) goes to position i: behind the live keys, each once
+      const unsigned i = (unsigned)(r * C::NCOL + gl);
+      const unsigned pos = (FULL || (int)i < n) ? start[r] + (w[r] >> 16) : i;
+      *reinterpret_cast<float*>(bytes + coop_addr<EPT>(pos)) = key[r];
     }
   }
   __syncthreads();
@@ -181,10 +183,6 @@ __device__ __forceinline__ void coop_sort(float (&key)[EPT], int wave, int lane,
     }
   };
   read_back();
-  if constexpr (!FULL) {
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) key[r] = (gl * EPT + r < n) ? key[r] : __builtin_inff();
-  }
   // ---- 5. fix-up inside the wave: g phases of odd-even transposition -------------------------------------------
   for (int phase = 0; phase < g; phase += 2) {
 #pragma unroll

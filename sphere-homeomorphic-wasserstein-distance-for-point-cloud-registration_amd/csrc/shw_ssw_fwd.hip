@@ -31,14 +31,18 @@ constexpr int min_waves_per_simd(int ept, int pmode) {
 constexpr bool forward_uses_bins(int ept) { return SHW_BINSORT != 0 && ept >= 8; }
 // LDS floats per wave: the sorted target row (64*EPT) and, with the bin sort, its 32*EPT counters in front of it
 constexpr int forward_lds_floats(int ept) { return forward_uses_bins(ept) ? (64 + SHW_BINSORT_NB_PER_EPT) * ept : 64 * ept; }
-constexpr int forward_min_waves(int ept, int pmode) {
+#ifndef SHW_FWD_MINW_PARTIAL
+#define SHW_FWD_MINW_PARTIAL 2     // clouds that do not fill the size class: 2 waves per SIMD, no spills (measured 0.371 -> 0.307 ms at N=2000)
+#endif
+constexpr int forward_min_waves(int ept, int pmode, bool full = true) {
+  if (forward_uses_bins(ept) && ept == 32 && !full) return SHW_FWD_MINW_PARTIAL;
   // bin sort: 12 KB of LDS per wave at EPT = 32 -> 13 waves per CU: ask the register allocator for 3 per SIMD
   return forward_uses_bins(ept) ? (ept == 32 ? SHW_FWD_MINW : (ept == 16 ? 5 : 6)) : min_waves_per_simd(ept, pmode);
 }
 
 // FULL: n == m == 64*EPT (no padding atoms): mask-free projection and the fast shift evaluation.
 template <int EPT, int WAVES, int PMODE, bool FULL>
-__global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE)) void ssw_forward_kernel(SswArgs A) {
+__global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE, FULL)) void ssw_forward_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool BINS = forward_uses_bins(EPT);
   const int lane = threadIdx.x & 63;
@@ -86,8 +90,10 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE)) void ssw
       for (int r = 0; r < EPT; ++r) u[r] = key[r];
     } else {
       sum_v = wave_sum(part, lane);
+      if constexpr (FULL || !BINS) {
 #pragma unroll
-      for (int r = 0; r < EPT; ++r) vbuf[r * kWave + lane] = key[r];
+        for (int r = 0; r < EPT; ++r) vbuf[r * kWave + lane] = key[r];
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -97,7 +103,15 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE)) void ssw
   best = u[0] + vbuf[lane] + sum_u - sum_v;
   const int k = 0;
 #else
-  const int k = solve_shift<EPT, PMODE, FULL>(u, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
+  int k;
+  if constexpr (FULL || !BINS) {
+    k = solve_shift<EPT, PMODE, FULL>(u, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
+  } else {
+    // any n: pre-rotated extended rows over the sort's scratch (counters + staging buffer are dead), target kept in
+    // registers for the rare rewrite
+    static_assert(ExtRows<EPT>::FLOATS <= forward_lds_floats(EPT), "extended rows must fit the sort's scratch");
+    k = solve_shift_ext<EPT, PMODE>(u, key, scratch, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
+  }
 #endif
   if (lane == 0) {
     A.slice_cost[s] = best / (float)A.n;

@@ -270,6 +270,150 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
   return k;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any n (not only n == 64*EPT): the sorted target as PRE-ROTATED, EXTENDED rows.
+//
+// The generic evaluation (shift_costs3 / target_unrolled) pays ~15 VALU per fetched target atom for the wrap-around
+// arithmetic (two conditional turns, a multiply, the slot computation).  Instead the target is written to LDS already
+// rotated to the first guess kc of the shift and with the turns added:
+//     ext[E] = v_ext(E - M + kc),   E in [0, n + 2M),   v_ext(q) = v[q mod n] + floor(q / n),   M = EPT,
+// laid out [E mod EPT][E div EPT] with 66 columns per row (64 lanes + the halo).  A shift k = kc + d with |d| < M
+// then reads ext[e + d + delta + M] for source atom e: no wrap, no turn, every address = lane*4 + a wave-uniform
+// offset -- 1 VALU per fetch.  The search seldom leaves |d| < M (the first guess is exact for evenly spaced
+// targets and galloping starts with steps 1, 2, 4, ...); when it does the rows are rewritten around the new k.
+// ---------------------------------------------------------------------------------------------
+template <int EPT>
+struct ExtRows {
+  static constexpr int M = EPT;                 // half width of the halo = reach of the shift without a rewrite
+  static constexpr int RS = 66;                 // columns per row: (64*EPT + 2M) / EPT
+  static constexpr int FLOATS = EPT * RS;
+  static constexpr int TRASH = ((EPT - 1) * RS + 65) * 4;      // byte offset of the last slot: never a valid E for n < 64*EPT
+};
+
+// v[r] = sorted target at position lane*EPT + r (anything at positions >= n).  n > M required (size classes give n > 32*EPT).
+template <int EPT>
+__device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext, int lane, int n, int kc) {
+  typedef ExtRows<EPT> X;
+  constexpr int LOG = __builtin_ctz(EPT);
+  // c1 = (M - kc) mod n and the turn s it absorbs: ext[p + c1] = v[p] - s, or, past the end, ext[p + c1 - n] = v[p] - s - 1
+  const int t = X::M - kc;                                       // in [M - n, M + n]
+  const int s = t < 0 ? -1 : (t >= n ? 1 : 0);
+  const int c1 = t - s * n;                                      // in [0, n)
+  const int c2 = c1 - n;                                         // in [-n, 0)
+  const int c1h = c1 >> LOG, c1l = c1 & (EPT - 1);
+  const int c2h = c2 >> LOG, c2l = c2 & (EPT - 1);               // floor division
+  const float vn = (float)(-s), vw = (float)(-s - 1);
+  char* bytes = reinterpret_cast<char*>(ext);
+  const int lane4 = lane << 2;
+  const int first_wrapped = n - c1;                              // positions p >= this wrap
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int a1 = r + c1l, a2 = r + c2l;                        // scalars
+    const int off_n = (((a1 & (EPT - 1)) * X::RS) + c1h + (a1 >> LOG)) << 2;
+    const int off_w = (((a2 & (EPT - 1)) * X::RS) + c2h + (a2 >> LOG)) << 2;
+    const int pos = lane * EPT + r;
+    const bool wrap = pos >= first_wrapped;
+    int off = wrap ? off_w : off_n;
+    off = pos < n ? off + lane4 : X::TRASH;
+    *reinterpret_cast<float*>(bytes + off) = v[r] + (wrap ? vw : vn);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // halo: ext[n + l] = ext[l] + 1 for l < 2M (one entry per lane; 2M <= 64)
+  {
+    const int src = lane, dst = n + lane;
+    const int so = (((src & (EPT - 1)) * X::RS) + (src >> LOG)) << 2;
+    const int d_o = (((dst & (EPT - 1)) * X::RS) + (dst >> LOG)) << 2;
+    const float x = *reinterpret_cast<const float*>(bytes + so);
+    *reinterpret_cast<float*>(bytes + (lane < 2 * X::M ? d_o : X::TRASH)) = x + 1.f;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// c(k-1), c(k), c(k+1) for k = kc + d, |d| < M, on registers [r_base, r_base + NR) of every lane (u holds those NR
+// source atoms; atoms at positions >= n are masked out).  Sums over the wave, valid in every lane.
+template <int EPT, int PMODE, int NR = EPT>
+__device__ __forceinline__ void shift_costs3_ext(const float (&u)[NR], const float* ext, int lane, int n, int d,
+                                                 float p, int p_int, float& cm, float& c0, float& cp, int r_base = 0) {
+  typedef ExtRows<EPT> X;
+  constexpr int LOG = __builtin_ctz(EPT);
+  const int base = d - 1 + X::M + r_base;                        // >= 0, wave-uniform
+  const int bl = base & (EPT - 1), bh = base >> LOG;
+  const char* rows = reinterpret_cast<const char*>(ext) + (lane << 2);
+  auto fetch = [&](int j) -> float {                             // j compile-time after unrolling
+    const int a = bl + j;                                        // scalar
+    const int off = (((a & (EPT - 1)) * X::RS) + bh + (a >> LOG)) << 2;
+    return *reinterpret_cast<const float*>(rows + off);
+  };
+  const int live_regs = n - lane * EPT - r_base;                 // registers j < live_regs hold real atoms
+  float sm = 0.f, s0 = 0.f, sp = 0.f;
+  float prev = fetch(0), cur = fetch(1);
+  constexpr int CH = NR < 8 ? NR : 8;
+#pragma unroll
+  for (int r0 = 0; r0 < NR; r0 += CH) {
+    float nxt[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) nxt[j] = fetch(r0 + j + 2);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const bool live = (r0 + j) < live_regs;
+      const float a = pow_abs<PMODE>(u[r0 + j] - prev, p, p_int);
+      const float b = pow_abs<PMODE>(u[r0 + j] - cur, p, p_int);
+      const float c = pow_abs<PMODE>(u[r0 + j] - nxt[j], p, p_int);
+      sm += live ? a : 0.f;
+      s0 += live ? b : 0.f;
+      sp += live ? c : 0.f;
+      prev = cur;
+      cur = nxt[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cm = wave_sum_uniform(sm, lane & 63);
+  c0 = wave_sum_uniform(s0, lane & 63);
+  cp = wave_sum_uniform(sp, lane & 63);
+}
+
+// solve_shift on extended rows (one wave owns the slice).  v = the sorted target in registers (kept for rewrites).
+template <int EPT, int PMODE>
+__device__ __forceinline__ int solve_shift_ext(const float (&u)[EPT], const float (&v)[EPT], float* ext, int lane, int n,
+                                               float sum_u, float sum_v, float p, int p_int, float& best) {
+  typedef ExtRows<EPT> X;
+  int lo = -n, hi = n;
+  float guess = rintf(sum_u - sum_v);
+  guess = fminf(fmaxf(guess, (float)lo), (float)hi);
+  int k = __builtin_amdgcn_readfirstlane((int)guess);
+  int kc = k;
+  ext_rows_write<EPT>(v, ext, lane, n, kc);
+  bool lo_tight = false, hi_tight = false;
+  int step = 1;
+  float cm, c0, cp;
+  for (int it = 0; it < 64; ++it) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    if (k - kc >= X::M || kc - k >= X::M) {                      // wave-uniform: re-centre the rows on k
+      kc = k;
+      ext_rows_write<EPT>(v, ext, ln, n, kc);
+    }
+    shift_costs3_ext<EPT, PMODE>(u, ext, ln, n, k - kc, p, p_int, cm, c0, cp);
+    const bool right = (cp < c0) && (k < hi);
+    const bool left = !right && (cm < c0) && (k > lo);
+    if (!right && !left) break;
+    if (right) {
+      lo = k + 1;
+      lo_tight = true;
+      if (hi_tight) { k = lo + ((hi - lo) >> 1); }
+      else { k = min(k + step, hi); step <<= 1; }
+    } else {
+      hi = k - 1;
+      hi_tight = true;
+      if (lo_tight) { k = lo + ((hi - lo) >> 1); }
+      else { k = max(k - step, lo); step <<= 1; }
+    }
+    k = __builtin_amdgcn_readfirstlane(k);
+  }
+  best = c0;
+  return k;
+}
+
 // Project the cloud onto the slice's circle: lane owns points r*64 + lane (coalesced 12-byte
 // records).  Padding keys are +inf so that they sort behind every real coordinate.
 // CHAINED: make the addresses of a chunk depend (through an empty asm) on the last coordinate of the chunk
