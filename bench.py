@@ -179,8 +179,9 @@ def main():
     # ---- roofline of the dominant kernel (ssw_forward_kernel), HIP events on the launch stream, measured BEFORE
     #      the timed region: it also brings the GPU to its steady-state clocks, which 5 warm-up steps of 0.3 ms do not
     reps = max(20, min(args.steps, 200))
-    for _ in range(5):
+    for _ in range(100):                     # ~25 ms of launches: the clocks are up before anything is timed
         enqueue_loss(outs[0])
+    torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
@@ -298,24 +299,25 @@ def main():
     # guide); only valid for the workload it was measured on
     traffic = os.environ.get("SHW_BENCH_TRAFFIC_BYTES")
     if traffic is None and (Bl, N, Ll, p) == (64, 2048, 512, 2.0):
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r02_traffic.json",):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
-                    traffic = json.load(fh)["ssw_forward_kernel<32,4,2,true>"]["traffic_bytes"]
+                    traffic = json.load(fh)["ssw_forward_kernel<32,1,2,true>"]["traffic_bytes"]
                 break
             except Exception:
                 traffic = None
     result["roofline"] = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS, "traffic": float(traffic) if traffic else None,
-        "kernel": "ssw_forward_kernel<32,4,2,true>" if (N, p) == (2048, 2.0) else "ssw_forward_kernel",
+        "kernel": "ssw_forward_kernel<32,1,2,true>" if (N, p) == (2048, 2.0) else "ssw_forward_kernel",
         "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
         "secondary_model": {"unit": "compare-exchanges/s",
                             "achieved": Bl * Ll * 2 * (next_pow2(N) // 2) * stages(N) / (kernel_ms * 1e-3),
-                            "note": "two bitonic sorts of next_pow2(N) keys per slice; DESIGN.md section 4 prices the "
-                                    "VALU / LDS-crossbar work of one launch"},
-        "note": "compulsory HBM traffic is 0.06 B/point-pair: the kernel is VALU/LDS-crossbar bound (in-register "
-                "bitonic sort), not HBM bound; see DESIGN.md for the compare-exchange model",
+                            "note": "compare-exchanges of two bitonic sorts of next_pow2(N) keys per slice -- the unit "
+                                    "of round 1's network kernel, kept for comparison; the distribution sort of round 2 "
+                                    "does the same job with ~1/4 of them (DESIGN.md section 4)"},
+        "note": "compulsory HBM traffic is 0.06 B/point-pair: the kernel is VALU-issue / LDS bound (projection, "
+                "distribution sort through LDS, shift solve), not HBM bound; DESIGN.md section 4 has the VALU model",
         "point_pairs_per_s_kernel_only": Bl * N * Ll / (kernel_ms * 1e-3),
     }
 
