@@ -26,14 +26,17 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: these entry points are its only dynamic symbols */
+#define SHW_API __attribute__((visibility("default")))
+
 #define SHW_ABI_VERSION 2 /* 2: shw_ssw_backward_points takes per-pair upstream weights */
 #define SHW_MAX_POINTS 8192 /* per cloud, per pair */
 
 /* ABI version of the loaded library (== SHW_ABI_VERSION of the header it was built from). */
-int shw_abi_version(void);
+SHW_API int shw_abi_version(void);
 
 /* Largest point count per cloud the sort kernels accept (SHW_MAX_POINTS). */
-int shw_max_points(void);
+SHW_API int shw_max_points(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Direction frames.
@@ -42,7 +45,7 @@ int shw_max_points(void);
  * draw itself (`torch.randn`, :307) stays with the caller so the generator is consumed as in the reference.
  *   z (count, 3, 2) fp32 in, u (count, 3, 2) fp32 out (orthonormal columns).
  */
-int shw_stiefel_frames(const float* z, long count, float* u, void* stream);
+SHW_API int shw_stiefel_frames(const float* z, long count, float* u, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spherical sliced-Wasserstein, forward.
@@ -58,7 +61,7 @@ int shw_stiefel_frames(const float* z, long count, float* u, void* stream);
  * This entry point: uniform weights; n == m for p != 1; any n, m for p == 1; 1 <= n, m <= SHW_MAX_POINTS.
  * (n != m or weights with p != 1: shw_ssw_forward_general.)
  */
-int shw_ssw_forward(const float* xs, const float* xt, const float* dirs,
+SHW_API int shw_ssw_forward(const float* xs, const float* xt, const float* dirs,
                     int pairs, int n, int m, int slices, long u_pair_stride, float p,
                     float* slice_cost, int32_t* slice_shift, void* stream);
 
@@ -70,7 +73,7 @@ int shw_ssw_forward(const float* xs, const float* xt, const float* dirs,
  *   total     (2)     out : total[0] = sum_b pair_loss[b], total[1] = total[0] / pairs
  * Deterministic (fixed-order shuffle + serial tree, no atomics).
  */
-int shw_ssw_reduce(const float* slice_cost, int pairs, int slices, float scale,
+SHW_API int shw_ssw_reduce(const float* slice_cost, int pairs, int slices, float scale,
                    float* pair_loss, float* total, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -87,9 +90,9 @@ int shw_ssw_reduce(const float* slice_cost, int pairs, int slices, float scale,
  *   (a_, b_) = U_l^T xs[b,i]   (SURVEY.md 8a row A9), likewise for xt.
  * Deterministic: every gradient element is summed over slices in a fixed order by one thread.
  */
-size_t shw_ssw_coef_bytes(int pairs, int n, int m, int slices);
+SHW_API size_t shw_ssw_coef_bytes(int pairs, int n, int m, int slices);
 
-int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs,
+SHW_API int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs,
                          int pairs, int n, int m, int slices, long u_pair_stride, float p,
                          float* slice_cost, int32_t* slice_shift,
                          float* coef_s, float* coef_t, void* stream);
@@ -98,7 +101,7 @@ int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs,
  * d loss / d total[0] of shw_ssw_reduce's outputs; row b of both gradients is multiplied by
  * pair_w[b] + total_w[0] inside the kernel (a NULL term counts as 0; both NULL = 1).  Any number of pairs
  * (batches beyond 65535 pairs go out as several launches). */
-int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
+SHW_API int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
                             const float* coef_s, const float* coef_t,
                             int pairs, int n, int m, int slices, long u_pair_stride, float scale,
                             const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt, void* stream);
@@ -116,7 +119,7 @@ int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs,
  *   coef_s / coef_t as in shw_ssw_forward_grad, both NULL for a loss-only evaluation.
  * 1 <= n, m <= 4096 on this path.
  */
-int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
+SHW_API int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
                             const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                             int pairs, int n, int m, int slices, long u_pair_stride, float p,
                             float* slice_cost, float* slice_theta, float* coef_s, float* coef_t, void* stream);
@@ -134,17 +137,17 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
  *   original point order; shw_esw_backward_points turns them into
  *   grad_x[b,i,:] = sum_l slice_w[b,l] * coef[b,l,i] * theta[b,l,:]  (slice_w = upstream gradient of S).
  */
-int shw_esw_forward(const float* xs, const float* xt, const float* thetas, int pairs, int n, int slices,
+SHW_API int shw_esw_forward(const float* xs, const float* xt, const float* thetas, int pairs, int n, int slices,
                     long theta_pair_stride, float p, float* slice_sum, float* coef_s, float* coef_t, void* stream);
 
-int shw_esw_backward_points(const float* thetas, const float* coef_s, const float* coef_t, const float* slice_w,
+SHW_API int shw_esw_backward_points(const float* thetas, const float* coef_s, const float* coef_t, const float* slice_w,
                             int pairs, int n, int slices, long theta_pair_stride,
                             float* grad_xs, float* grad_xt, void* stream);
 
 /* Gradient w.r.t. the directions (max_sliced_wasserstein_distance, Flow_cube.ipynb:294-323, ascends on them):
  *   grad_thetas[b,l,:] = slice_w[b,l] * sum_i (coef_s[b,l,i] * xs[b,i,:] + coef_t[b,l,i] * xt[b,i,:]),
  * always (pairs, slices, 3); directions shared by several pairs sum their rows on the host side. */
-int shw_esw_backward_dirs(const float* xs, const float* xt, const float* coef_s, const float* coef_t,
+SHW_API int shw_esw_backward_dirs(const float* xs, const float* xt, const float* coef_s, const float* coef_t,
                           const float* slice_w, int pairs, int n, int slices, float* grad_thetas, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -163,9 +166,9 @@ int shw_esw_backward_dirs(const float* xs, const float* xt, const float* coef_s,
  * The cost matrix is never stored unless asked for; the iteration count is fixed at enqueue time and the
  * convergence test is a device-side flag that turns the remaining launches into no-ops (no host sync).
  */
-size_t shw_sinkhorn_workspace_bytes(int pairs, int n, int m);
+SHW_API size_t shw_sinkhorn_workspace_bytes(int pairs, int n, int m);
 
-int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
+SHW_API int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
                          int norm_p, int cost_pow, float thresh, void* workspace, float* cost, float* plan,
                          float* cost_matrix, void* stream);
 
@@ -180,14 +183,14 @@ int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int n, int m
  *   pair_loss (pairs) out : mean_i min_xy[b,i] + mean_j min_yx[b,j]   (deterministic reduction)
  * All five outputs are required (the index arrays feed shw_chamfer_backward).  pairs <= 65535 (gridDim.y).
  */
-int shw_chamfer_forward(const float* x, const float* y, int pairs, int n, int m,
+SHW_API int shw_chamfer_forward(const float* x, const float* y, int pairs, int n, int m,
                         float* min_xy, int32_t* nn_xy, float* min_yx, int32_t* nn_yx,
                         float* pair_loss, void* stream);
 
 /* grad of sum_b w[b]*pair_loss[b] (w = per-pair upstream gradient, device pointer, (pairs)).
  * grad_x, grad_y must be zero-filled by the caller: the nearest-neighbour side of each term is
  * scattered with float atomics (sum order, hence the last bits, may vary from run to run). */
-int shw_chamfer_backward(const float* x, const float* y, const int32_t* nn_xy, const int32_t* nn_yx,
+SHW_API int shw_chamfer_backward(const float* x, const float* y, const int32_t* nn_xy, const int32_t* nn_yx,
                          const float* w, int pairs, int n, int m,
                          float* grad_x, float* grad_y, void* stream);
 
