@@ -125,6 +125,23 @@ SHW_API int shw_ssw_forward_general(const float* xs, const float* xt, const floa
                             float* slice_cost, float* slice_theta, float* coef_s, float* coef_t, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Circle level: optimal transport between rows of circle COORDINATES (numbers in [0, 1]), no projection.
+ * Replaces: binary_search_circle(u_values, v_values, u_weights, v_weights, p) (max_spherical_sliced_w.py:117-207)
+ * for p != 1 and emd1D_circle(u_values, v_values, u_weights, v_weights) (:210-247) for p == 1, called on
+ * (rows, n) / (rows, m) coordinate tensors -- the same kernels as the sliced entry points, their loaders reading
+ * one float per atom instead of projecting a point on a frame.
+ *   u (rows, n), v (rows, m); wu / wv weights (n) / (m) shared (stride 0) or per row (stride n / m), NULL = uniform;
+ *   cost (rows) out : W_p^p of every row;
+ *   aux  (rows) out, may be NULL : int32 optimal shift k* (equal sizes, p != 1) or median level (p == 1), or the
+ *                fp32 cut the bisection ended on (n != m or weights);
+ *   grad_u (rows*n), grad_v (rows*m) out, both NULL for a value-only call : d cost[row] / d u[row, i], / d v[row, j].
+ * Same size limits as the sliced entry points (8192; 4096 with weights or n != m and p != 1).
+ */
+SHW_API int shw_circle_ot(const float* u, const float* v, const float* wu, const float* wv, long wu_row_stride,
+                          long wv_row_stride, int rows, int n, int m, float p, float* cost, float* aux,
+                          float* grad_u, float* grad_v, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Euclidean sliced-Wasserstein (the notebooks' SWD baseline).
  * Replaces: sliced_wasserstein_distance (Wasserstein_flow_problem/Flow_cube.ipynb:280-292): projection on unit
  * directions, per-slice sort of both projected sequences, sum of |sorted difference|^p.

@@ -35,6 +35,9 @@ _SIGNATURES = {
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                                ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                                                ctypes.c_void_p]),
+    "shw_circle_ot": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                                     ctypes.c_void_p]),
     "shw_esw_forward": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                        ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_esw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,

@@ -187,9 +187,8 @@ __device__ __forceinline__ void binsort_place(float (&key)[EPT], const unsigned 
 // Sort the 64*EPT keys of a wave ascending (pads = +inf behind the n live keys).  Falls back to the bitonic network
 // when the data has runs longer than SHW_BINSORT_MAX_RUN.  scratch: 32*EPT counters followed by 64*EPT floats.
 template <int EPT, bool FULL>
-__device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, int n, float* scratch) {
-  unsigned* cnt = reinterpret_cast<unsigned*>(scratch);
-  float* buf = scratch + SHW_BINSORT_NB_PER_EPT * EPT;
+__device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, int n, float* counters, float* buf) {
+  unsigned* cnt = reinterpret_cast<unsigned*>(counters);
   unsigned w[EPT];
   const int g = binsort_histogram<EPT, FULL>(key, w, lane, n, cnt);
   if (g <= SHW_BINSORT_MAX_RUN) {
@@ -199,6 +198,12 @@ __device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, in
     wave_sort<EPT>(key, lane);
 #endif
   }
+}
+
+// counters and staging buffer contiguous: 32*EPT counters followed by 64*EPT floats
+template <int EPT, bool FULL>
+__device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, int n, float* scratch) {
+  wave_sort_binned<EPT, FULL>(key, lane, n, scratch, scratch + SHW_BINSORT_NB_PER_EPT * EPT);
 }
 
 }  // namespace shw

@@ -139,7 +139,7 @@ int shw_ssw_forward(const float* xs, const float* xt, const float* dirs, int pai
   if (pairs == 0 || slices == 0) return 0;
   shw::SswArgs A{};
   A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = slice_shift;
-  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride;
+  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride; A.pstride = 3;
   A.p = p; A.p_int = shw::small_integer_power(p);
   if (p == 1.f) return shw::dispatch_level_median(A, (hipStream_t)stream);
   return shw::dispatch_forward(A, (hipStream_t)stream);
@@ -182,7 +182,7 @@ int shw_ssw_forward_grad(const float* xs, const float* xt, const float* dirs, in
   shw::SswArgs A{};
   A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = slice_shift;
   A.coef_s = coef_s; A.coef_t = coef_t;
-  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride;
+  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride; A.pstride = 3;
   A.p = p; A.p_int = shw::small_integer_power(p);
   if (p == 1.f) return shw::dispatch_level_median(A, (hipStream_t)stream);
   return shw::dispatch_forward_grad(A, (hipStream_t)stream);
@@ -202,9 +202,32 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
   shw::SswArgs A{};
   A.xs = xs; A.xt = xt; A.dirs = dirs; A.slice_cost = slice_cost; A.slice_shift = nullptr;
   A.coef_s = coef_s; A.coef_t = coef_t;
-  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride;
+  A.pairs = pairs; A.n = n; A.m = m; A.slices = slices; A.u_pair_stride = u_pair_stride; A.pstride = 3;
   A.p = p; A.p_int = shw::small_integer_power(p);
   return shw::dispatch_general(A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, (hipStream_t)stream);
+}
+
+int shw_circle_ot(const float* u, const float* v, const float* wu, const float* wv, long wu_row_stride,
+                  long wv_row_stride, int rows, int n, int m, float p, float* cost, float* aux, float* grad_u,
+                  float* grad_v, void* stream) {
+  if (!u || !v || !cost) return (int)hipErrorInvalidValue;
+  if ((grad_u == nullptr) != (grad_v == nullptr)) return (int)hipErrorInvalidValue;
+  if (rows < 0 || n < 1 || m < 1 || !(p >= 1.f)) return (int)hipErrorInvalidValue;
+  if (rows == 0) return 0;
+  const bool general = wu || wv || (p != 1.f && n != m);
+  const int limit = general ? 4096 : SHW_MAX_POINTS;
+  if (n > limit || m > limit) return (int)hipErrorInvalidValue;
+  if ((wu_row_stride != 0 && wu_row_stride < n) || (wv_row_stride != 0 && wv_row_stride < m)) return (int)hipErrorInvalidValue;
+  // a row is a "pair" with ONE slice whose atoms already are circle coordinates (dirs = NULL, one float per atom)
+  shw::SswArgs A{};
+  A.xs = u; A.xt = v; A.dirs = nullptr; A.slice_cost = cost; A.slice_shift = nullptr;
+  A.coef_s = grad_u; A.coef_t = grad_v;
+  A.pairs = rows; A.n = n; A.m = m; A.slices = 1; A.u_pair_stride = 0; A.pstride = 1;
+  A.p = p; A.p_int = shw::small_integer_power(p);
+  if (general) return shw::dispatch_general(A, wu, wv, wu_row_stride, wv_row_stride, aux, (hipStream_t)stream);
+  A.slice_shift = reinterpret_cast<int32_t*>(aux);
+  if (p == 1.f) return shw::dispatch_level_median(A, (hipStream_t)stream);
+  return grad_u ? shw::dispatch_forward_grad(A, (hipStream_t)stream) : shw::dispatch_forward(A, (hipStream_t)stream);
 }
 
 int shw_ssw_backward_points(const float* xs, const float* xt, const float* dirs, const float* coef_s,

@@ -31,17 +31,15 @@ __global__ __launch_bounds__(W * 64) void ssw_forward_coop_kernel(SswArgs A) {
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n;
 
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
   coop_zero_counters<EPT, W>(cnt, gl);
   float u[EPT], key[EPT];
   float part_u = 0.f, part_v = 0.f;
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {                     // 0: source -> registers, 1: target -> LDS rows
-    const float* X = (which == 0 ? A.xs : A.xt) + (long)b * n * 3;
+    const float* X = (which == 0 ? A.xs : A.xt) + (long)b * n * A.pstride;
     int g2 = gl;
     asm volatile("" : "+v"(g2));
     const float part = load_coords<EPT, FULL, false, C::NCOL>(X, n, g2, U, key);

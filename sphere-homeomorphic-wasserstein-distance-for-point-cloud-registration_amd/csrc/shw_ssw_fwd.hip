@@ -55,16 +55,14 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE, FULL)) vo
   if (s >= A.pairs * A.slices) return;            // wave-uniform
   const int b = s / A.slices, l = s - b * A.slices;
 
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];       // (3,2) row-major: U[2*d + k]
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
   float key[EPT], u[EPT];
   float sum_v = 0.f, sum_u = 0.f;
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {        // 0: source -> registers, 1: target -> LDS
-    const float* X = which == 0 ? A.xs + (long)b * A.n * 3 : A.xt + (long)b * A.m * 3;
+    const float* X = which == 0 ? A.xs + (long)b * A.n * A.pstride : A.xt + (long)b * A.m * A.pstride;
     const int count = which == 0 ? A.n : A.m;
     // Opaque copy of the lane id: keeps the compiler from hoisting the lane-dependent constants of the sort (and
     // the point offsets) out of this loop and holding them in VGPRs.
@@ -171,10 +169,8 @@ __global__ __launch_bounds__(W * 64, 4) void ssw_forward_mw_kernel(SswArgs A) {
   const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);  // one workgroup per (pair, slice)
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n;
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
   float u[EPT], key[EPT];
   float part_u = 0.f, part_v = 0.f;
@@ -182,11 +178,11 @@ __global__ __launch_bounds__(W * 64, 4) void ssw_forward_mw_kernel(SswArgs A) {
   const int chunk_live = max(0, min(CHUNK, n - first));
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {                    // 0: source -> registers, 1: target -> LDS
-    const float* X = (which == 0 ? A.xs : A.xt) + (long)b * n * 3;
+    const float* X = (which == 0 ? A.xs : A.xt) + (long)b * n * A.pstride;
     const int base = min(first, n - 1);                        // keep the addresses of an empty chunk in bounds
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const float part = load_coords<EPT, FULL>(X + (long)base * 3, n - base, ln, U, key, chunk_live);
+    const float part = load_coords<EPT, FULL>(X + (long)base * A.pstride, n - base, ln, U, key, chunk_live);
     wave_sort<EPT>(key, ln);
     merge_across_waves<W>(key, buf, wave, ln);
     if (which == 0) {
@@ -289,17 +285,25 @@ static int launch_forward(SswArgs& A, hipStream_t stream) {
 }
 
 int dispatch_forward_coop(SswArgs& A, hipStream_t stream);       // shw_ssw_coop.hip
+int dispatch_forward2(SswArgs& A, hipStream_t stream);           // shw_ssw_fwd2.hip
 
-// Which loss-only kernel serves p != 1:
-//   <= 2048 (padded) points : one wave per slice (ssw_forward_kernel: in-wave distribution sort at >= 8 keys per lane)
-//   >  2048                 : W = padded / 2048 waves per slice, cooperative distribution sort (shw_ssw_coop.hip)
-// SHW_FORWARD_KERNEL=network (diagnostic, used by the tests): the multi-wave bitonic kernel above 2048 points;
-// SHW_FORWARD_KERNEL=coop: the cooperative kernel from 2048 points on.
+// Which loss-only kernel serves p != 1 (measured, profiles/r02_ab_twowave_fwd.txt):
+//   n == m == 2048 exactly    : one wave per slice (ssw_forward_kernel, in-wave distribution sort) -- 0.228 ms at config 3
+//                               against 0.240 for two waves, at the price of 25 spilled VGPRs
+//   512..2048 (padded) points : otherwise two waves per slice, one cloud each (shw_ssw_fwd2.hip): no spills, and faster
+//                               wherever the cloud does not fill its size class (N=2000: 0.306 vs 0.330 ms)
+//   > 2048                    : W = padded / 2048 waves per slice, cooperative distribution sort (shw_ssw_coop.hip)
+//   < 512                     : one wave per slice, register network below 8 keys per lane
+// SHW_FORWARD_KERNEL (diagnostic, read once; the tests run every family): onewave = never two waves;
+// twowave = two waves also at 2048 exactly; network = the bitonic multi-wave kernel above 2048 points;
+// coop = the cooperative kernel from 2048 points on.
 static int forward_family() {
   static const int fam = [] {
     const char* e = getenv("SHW_FORWARD_KERNEL");
     if (e && e[0] == 'n') return 1;       // network
     if (e && e[0] == 'c') return 2;       // coop from 2048
+    if (e && e[0] == 't') return 3;       // twowave
+    if (e && e[0] == 'o') return 4;       // onewave
     return 0;
   }();
   return fam;
@@ -311,6 +315,10 @@ int dispatch_forward(SswArgs& A, hipStream_t stream) {
     const int padded = next_pow2(A.n > A.m ? A.n : A.m);
     const int fam = forward_family();
     if ((fam == 0 && padded > 2048) || (fam == 2 && padded >= 2048)) return dispatch_forward_coop(A, stream);
+    if (padded >= 512 && padded <= 2048 && fam != 4 && fam != 1) {
+      const bool headline = (A.n == 2048 && A.m == 2048);
+      if (fam == 3 || (fam == 0 && !headline)) return dispatch_forward2(A, stream);
+    }
   }
 #endif
   switch (ept_for(A.n, A.m)) {

@@ -429,13 +429,11 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
   const SswArgs& A = G.base;
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n, m = A.m;
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {                  // 0: target, 1: source
-    const float* X = which == 0 ? A.xt + (long)b * m * 3 : A.xs + (long)b * n * 3;
+    const float* X = which == 0 ? A.xt + (long)b * m * A.pstride : A.xs + (long)b * n * A.pstride;
     const int count = which == 0 ? m : n;
     const float* W = which == 0 ? G.wv : G.wu;
     const long wstride = which == 0 ? G.wv_pair_stride : G.wu_pair_stride;
@@ -488,14 +486,12 @@ __device__ __forceinline__ void prepare_from_indices(const GeneralArgs& G, int s
                                                      int (&sidx)[EPT], int (&tidx)[EPT]) {
   const SswArgs& A = G.base;
   const int b = s / A.slices, l = s - b * A.slices;
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {
     const int count = which == 0 ? A.m : A.n;
-    const float* X = which == 0 ? A.xt + (long)b * count * 3 : A.xs + (long)b * count * 3;
+    const float* X = which == 0 ? A.xt + (long)b * count * A.pstride : A.xs + (long)b * count * A.pstride;
     const unsigned short* perm = reinterpret_cast<const unsigned short*>(
         which == 0 ? A.coef_t + (long)s * A.m : A.coef_s + (long)s * A.n);
     float* dval = which == 0 ? t_val : s_val;
@@ -838,7 +834,8 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   solve.cut_scratch = A.coef_s;                              // first word of each slice's own coefficient row
   solve.cut_stride = A.n;
   solve.cut_scratch_t = A.coef_t;
-  const int handoff = (uniform && A.n >= 2 && A.m >= 2) ? 1 : 0;
+  // (coordinate-row mode re-sorts in the gradient launch: the hand-off re-projects gathered POINTS)
+  const int handoff = (uniform && A.n >= 2 && A.m >= 2 && A.pstride == 3) ? 1 : 0;
   solve.idx_handoff = handoff;
   GeneralArgs eval = G;
   eval.cut_scratch = A.coef_s;

@@ -62,17 +62,15 @@ __global__ __launch_bounds__(WAVES * 64, grad_waves_per_simd(EPT)) void ssw_forw
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n;
 
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
   float u[EPT];
   unsigned upair[HALF];                              // original indices of the sorted source, two per word
   float sum_v = 0.f, sum_u = 0.f;
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {
-    const float* X = which == 0 ? A.xs + (long)b * n * 3 : A.xt + (long)b * A.m * 3;
+    const float* X = which == 0 ? A.xs + (long)b * n * A.pstride : A.xt + (long)b * A.m * A.pstride;
     const int count = which == 0 ? n : A.m;
     int ln = lane;
     asm volatile("" : "+v"(ln));

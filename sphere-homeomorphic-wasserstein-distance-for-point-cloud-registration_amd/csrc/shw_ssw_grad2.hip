@@ -45,16 +45,14 @@ __global__ __launch_bounds__(128, grad2_waves_per_simd(EPT)) void ssw_forward_gr
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n;                                               // == A.m on this path
 
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
   // ---- phase 1 + 2 ------------------------------------------------------------------------------------------
   {
     float val[EPT];
     int idx[EPT];
-    const float* X = (wave ? A.xt : A.xs) + (long)b * n * 3;
+    const float* X = (wave ? A.xt : A.xs) + (long)b * n * A.pstride;
     const float part = sorted_with_indices_binned<EPT, true, FULL>(X, n, lane, U, reinterpret_cast<unsigned*>(my_row + ROW),
                                                        my_row, val, idx);
     const float total = wave_sum_uniform(part, lane);

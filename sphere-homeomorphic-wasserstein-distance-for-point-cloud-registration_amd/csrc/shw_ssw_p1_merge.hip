@@ -79,15 +79,13 @@ ssw_level_median_merge_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n, m = A.m, total_live = n + m;
 
-  const float* Ul = A.dirs + (long)b * A.u_pair_stride + (long)l * 6;
   float U[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
   // ---- project + sort: wave 0 the source, wave 1 the target -------------------------------------
   unsigned pk[EPT];
   {
-    const float* X = wave == 0 ? A.xs + (long)b * n * 3 : A.xt + (long)b * m * 3;
+    const float* X = wave == 0 ? A.xs + (long)b * n * A.pstride : A.xt + (long)b * m * A.pstride;
     const int count = wave == 0 ? n : m;
     if constexpr (GRAD) {
       float val[EPT];

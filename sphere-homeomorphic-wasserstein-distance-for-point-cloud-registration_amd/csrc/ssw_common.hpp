@@ -33,6 +33,8 @@ struct SswArgs {
   float* coef_s;   // forward_grad only
   float* coef_t;
   int pairs, n, m, slices;
+  int pstride;     // floats per point: 3 (clouds, projected on the slice's frame) or 1 (rows of circle coordinates: the
+                   // circle-level entry point shw_circle_ot; dirs is NULL then and a "pair" is one row)
   long u_pair_stride;
   float p;
   int p_int;       // p if p is a small integer (2..8), else 0
@@ -49,6 +51,19 @@ __device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// The slice's frame U (3,2) row-major, wave-uniform.  Coordinate-row mode (dirs == NULL): U[0] = NaN tells load_coords to
+// take the input values as circle coordinates.
+__device__ __forceinline__ void load_frame(const float* dirs, long offset, float (&U)[6]) {
+  if (dirs) {
+    const float* Ul = dirs + offset;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) U[i] = Ul[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) U[i] = __builtin_nanf("");
+  }
 }
 
 // circle coordinate of one projected point (reference :274-279):
@@ -428,6 +443,18 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
   // real atoms; they differ only for the trailing chunks of the multi-wave kernel
   if (live_count < 0) live_count = count;
   float acc = 0.f;
+  if (U[0] != U[0]) {
+    // coordinate-row mode (shw_circle_ot): X holds circle coordinates, one float per atom
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * NCOL + lane;
+      const float c = X[FULL ? i : min(i, count - 1)];
+      const bool live = FULL || (i < live_count);
+      acc += live ? c : 0.f;
+      key[r] = live ? c : __builtin_inff();
+    }
+    return acc;
+  }
   constexpr int CH = EPT < 8 ? EPT : 8;            // 8 points (24 loads) in flight per lane
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
@@ -550,6 +577,7 @@ __device__ __forceinline__ void unpack_sorted_words(const unsigned (&pk)[EPT], c
               (FULL || (int)(pk[EPT - 1] & PK::IDX_MASK) < count);
     prev_eq = (lane > 0) && (((pk[0] ^ prv) >> PK::IDX_BITS) == 0) && (FULL || (int)(pk[0] & PK::IDX_MASK) < count);
   }
+  const bool next_eq = collide;                           // (last atom of this lane, first atom of the next)
 #pragma unroll
   for (int r = 1; r < EPT; ++r) {
     const bool eq = (((pk[r] ^ pk[r - 1]) >> PK::IDX_BITS) == 0) && (FULL || (int)(pk[r] & PK::IDX_MASK) < count);
@@ -557,6 +585,8 @@ __device__ __forceinline__ void unpack_sorted_words(const unsigned (&pk)[EPT], c
     collide |= eq;
     prev_eq = eq;
   }
+  chain |= prev_eq && next_eq;                            // ... (EPT-2, EPT-1, first of the next lane)
+  if constexpr (EPT == 1) chain |= collide;               // one atom per lane: every collision touches a lane boundary
   // (the packed words are dead from here on: index and gathered coordinate take their registers)
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {

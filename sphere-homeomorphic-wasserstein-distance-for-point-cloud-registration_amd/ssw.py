@@ -283,3 +283,68 @@ def sliced_wasserstein_sphere_fast(Xs, Xt, num_projections, device, u_weights=No
     """Reference batched signature (_fast.py:298).  Xs (B,n,3), Xt (B,m,3) -> shape-[1] tensor."""
     U = draw_directions(num_projections, device, batch=Xs.shape[0], d=Xs.shape[2])
     return sliced_cost(Xs, Xt, U, p=p, u_weights=u_weights, v_weights=v_weights)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# circle level: the reference's binary_search_circle / emd1D_circle on rows of circle coordinates
+# ------------------------------------------------------------------------------------------------------------------
+class _CircleOT(torch.autograd.Function):
+    """(rows,n), (rows,m) circle coordinates -> (rows,) W_p^p.  One launch; the gradient rows come out of the same
+    kernels as d cost / d coordinate (what the sliced path calls its coefficient rows)."""
+
+    @staticmethod
+    def forward(ctx, u, v, p, wu, wv, need_grad):
+        lib = _lib.load()
+        rows, n = u.shape
+        m = v.shape[1]
+        dev = u.device
+        uc, vc = u.contiguous(), v.contiguous()
+        cost = torch.empty(rows, dtype=torch.float32, device=dev)
+        gu = torch.empty(rows, n, dtype=torch.float32, device=dev) if need_grad else None
+        gv = torch.empty(rows, m, dtype=torch.float32, device=dev) if need_grad else None
+
+        def wargs(w, cnt):
+            if w is None:
+                return None, 0
+            return w.data_ptr(), (0 if w.dim() == 1 else cnt)
+        wu_p, wu_s = wargs(wu, n)
+        wv_p, wv_s = wargs(wv, m)
+        with torch.cuda.device(dev):
+            _lib.check(lib.shw_circle_ot(uc.data_ptr(), vc.data_ptr(), wu_p, wv_p, wu_s, wv_s, rows, n, m, float(p),
+                                         cost.data_ptr(), None, gu.data_ptr() if need_grad else None,
+                                         gv.data_ptr() if need_grad else None, _stream_ptr(dev)), "shw_circle_ot")
+        if need_grad:
+            ctx.save_for_backward(gu, gv)
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        gu, gv = ctx.saved_tensors
+        w = g.to(torch.float32).unsqueeze(1)
+        return gu * w, gv * w, None, None, None, None
+
+
+def _check_rows(name, t):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise TypeError(f"{name} must be a float32 device tensor (no CPU fallback)")
+    if t.dim() not in (1, 2):
+        raise ValueError(f"{name} must be (n,) or (rows, n) circle coordinates")
+    return t.unsqueeze(0) if t.dim() == 1 else t
+
+
+def binary_search_circle(u_values, v_values, u_weights=None, v_weights=None, p=1):
+    """Reference `binary_search_circle` (max_spherical_sliced_w.py:117): circular OT cost W_p^p between rows of circle
+    coordinates in [0, 1], (rows, n) and (rows, m) -> (rows,).  p == 1 takes the level-median formula like the
+    reference's own dispatch in sliced_cost (:281-284).  Differentiable w.r.t. the coordinates."""
+    u, v = _check_rows("u_values", u_values), _check_rows("v_values", v_values)
+    if u.shape[0] != v.shape[0]:
+        raise ValueError("u_values and v_values need the same number of rows")
+    wu = _check_weights("u_weights", u_weights, u.shape[1], u.shape[0], u.device)
+    wv = _check_weights("v_weights", v_weights, v.shape[1], u.shape[0], u.device)
+    need_grad = torch.is_grad_enabled() and (u.requires_grad or v.requires_grad)
+    return _CircleOT.apply(u, v, float(p), wu, wv, need_grad)
+
+
+def emd1D_circle(u_values, v_values, u_weights=None, v_weights=None, p=1):
+    """Reference `emd1D_circle` (:210): circular W_1 by the level-median formula (p = 1), otherwise the bisection."""
+    return binary_search_circle(u_values, v_values, u_weights, v_weights, p)
