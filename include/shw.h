@@ -168,7 +168,7 @@ SHW_API int shw_esw_backward_dirs(const float* xs, const float* xt, const float*
                           const float* slice_w, int pairs, int n, int slices, float* grad_thetas, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Log-domain Sinkhorn distance (comparison metric; forward only).
+ * Log-domain Sinkhorn distance (comparison metric); value-only entry point.
  * Replaces: log_Sinkhorn_Distance_Loss.forward and log_N_Sinkhorn_Distance_Loss.forward
  * (/root/reference/Comparison_Wasserstein_with_Chamfer_distance/losses/sinkhorn.py:14-63, :104-157), called at
  * main_rotation.py:207-211.
@@ -188,6 +188,25 @@ SHW_API size_t shw_sinkhorn_workspace_bytes(int pairs, int n, int m);
 SHW_API int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
                          int norm_p, int cost_pow, float thresh, void* workspace, float* cost, float* plan,
                          float* cost_matrix, void* stream);
+
+/* Log-domain Sinkhorn with gradients w.r.t. both clouds.
+ * Replaces: autograd through log_Sinkhorn_Distance_Loss.forward (sinkhorn.py:35-49: the iterations are differentiable).
+ * shw_sinkhorn_forward_train runs the same iterations and keeps the trajectory of the duals (u_t, v_t), t = 0..T, in
+ * `workspace` (shw_sinkhorn_train_workspace_bytes(pairs, n, m, max_iter) bytes: 2 (max_iter + 2) pairs (n + m) floats);
+ * shw_sinkhorn_backward walks it from t = T down to 1, two kernels per iteration, recomputing the transport weights
+ * from the points (nothing dense is stored), every gradient row owned by one thread (deterministic):
+ *   grad_cost (pairs) in : upstream gradient of cost[b];  grad_x (pairs, n, 3), grad_y (pairs, m, 3) out (overwritten).
+ * The workspace must be passed unchanged from the forward to the backward call (same sizes, eps, max_iter, norms).
+ */
+SHW_API size_t shw_sinkhorn_train_workspace_bytes(int pairs, int n, int m, int max_iter);
+
+SHW_API int shw_sinkhorn_forward_train(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
+                                       int norm_p, int cost_pow, float thresh, void* workspace, float* cost,
+                                       void* stream);
+
+SHW_API int shw_sinkhorn_backward(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
+                                  int norm_p, int cost_pow, void* workspace, const float* grad_cost, float* grad_x,
+                                  float* grad_y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Chamfer distance (comparison baseline).

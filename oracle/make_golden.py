@@ -124,6 +124,31 @@ def g8_phi_max_wrappers(ref, ref_fast):
     np.savez_compressed(os.path.join(OUT, "g8_phi_max.npz"), **out)
 
 
+def g7b_sinkhorn_gradients():
+    """G7b: gradients of the REAL log_Sinkhorn_Distance_Loss / log_N_... w.r.t. both clouds (the reference's forward is
+    differentiable through its unrolled iterations, sinkhorn.py:35-49).  Same inputs as G7."""
+    sk = _load("ref_sinkhorn", "/root/reference/Comparison_Wasserstein_with_Chamfer_distance/losses/sinkhorn.py")
+    g = torch.Generator().manual_seed(20250107)
+    xs = F.normalize(torch.randn(2, 96, 3, generator=g), dim=-1)
+    ys = xs @ rot_x(30).T + 0.05 * torch.randn(2, 96, 3, generator=g)
+    ys = ys[:, :80].contiguous()
+    out = {"x": _np(xs), "y": _np(ys)}
+    cases = {"eps0.05_it60": (sk.log_Sinkhorn_Distance_Loss, dict(eps=0.05, max_iter=60, batch_reduction="sum", type_of_cost_norm="L2")),
+             "eps0.01_it100": (sk.log_Sinkhorn_Distance_Loss, dict(eps=0.01, max_iter=100, batch_reduction="sum", type_of_cost_norm="L2")),
+             "eps0.1_it5": (sk.log_Sinkhorn_Distance_Loss, dict(eps=0.1, max_iter=5, batch_reduction="mean", type_of_cost_norm="L2")),
+             "L1_eps0.05_it30": (sk.log_Sinkhorn_Distance_Loss, dict(eps=0.05, max_iter=30, batch_reduction="sum", type_of_cost_norm="L1")),
+             "N2_eps0.05_it30": (sk.log_N_Sinkhorn_Distance_Loss, dict(eps=0.05, max_iter=30, batch_reduction="mean", type_of_cost_norm="L2",
+                                                                         type_of_Wasserstein_N="2"))}
+    for tag, (cls, kw) in cases.items():
+        a, b = xs.clone().requires_grad_(True), ys.clone().requires_grad_(True)
+        cost = cls(**kw)(a, b, "cpu")[0]
+        cost.backward()
+        out[f"cost_{tag}"] = _np(cost)
+        out[f"gx_{tag}"] = _np(a.grad)
+        out[f"gy_{tag}"] = _np(b.grad)
+    np.savez_compressed(os.path.join(OUT, "g7b_sinkhorn_grad.npz"), **out)
+
+
 def notebook_cell_namespace(path, needle):
     """exec the SOURCE TEXT of the notebook code cell that contains `needle` (definitions only) and return its
     namespace.  The notebook cannot be imported (its `datas` / `losses` modules are not shipped),
@@ -190,6 +215,8 @@ def main(only=()):
             g8_phi_max_wrappers(ref, ref_fast)
         if "g9" in only:
             g9_notebook_euclidean_sw()
+        if "g7b" in only:
+            g7b_sinkhorn_gradients()
         for f in sorted(os.listdir(OUT)):
             print(f, os.path.getsize(os.path.join(OUT, f)))
         return 0
@@ -351,6 +378,7 @@ def main(only=()):
 
     g8_phi_max_wrappers(ref, ref_fast)
     g9_notebook_euclidean_sw()
+    g7b_sinkhorn_gradients()
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

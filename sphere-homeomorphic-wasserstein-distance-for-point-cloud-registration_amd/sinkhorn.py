@@ -5,8 +5,9 @@ main_rotation.py:207-211):
     criteria = log_Sinkhorn_Distance_Loss(eps, max_iter, batch_reduction='sum', type_of_cost_norm='L2')
     loss, P, C = criteria(template, source, device)
 
-Forward only: the reference differentiates through its unrolled iterations, its callers only evaluate the value;
-a tensor that requires grad is rejected rather than silently detached.  The dense plan P and cost matrix C the
+Differentiable like the reference (its forward is autograd-visible through the unrolled iterations, :35-49): when a
+cloud requires grad the iterations keep the trajectory of the duals and `backward` walks it (shw_sinkhorn_backward;
+round 2).  The dense plan P and cost matrix C the
 reference returns are produced on request (`return_plan=True`, the default, keeps the call a drop-in;
 `return_plan=False` returns (cost, None, None) and never allocates the two (B, n, m) tensors)."""
 from __future__ import annotations
@@ -17,14 +18,54 @@ from . import _lib
 from .ssw import _check_cloud, _stream_ptr
 
 
+class _SinkhornCosts(torch.autograd.Function):
+    """(B,n,3), (B,m,3) -> (B,) costs with the gradient through the unrolled iterations."""
+
+    @staticmethod
+    def forward(ctx, x, y, eps, max_iter, norm_p, cost_pow, thresh):
+        lib = _lib.load()
+        B, n, _ = x.shape
+        m = y.shape[1]
+        dev = x.device
+        xc, yc = x.contiguous(), y.contiguous()
+        ws = torch.empty(lib.shw_sinkhorn_train_workspace_bytes(B, n, m, max_iter), dtype=torch.uint8, device=dev)
+        cost = torch.empty(B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.shw_sinkhorn_forward_train(xc.data_ptr(), yc.data_ptr(), B, n, m, eps, max_iter, norm_p,
+                                                      cost_pow, thresh, ws.data_ptr(), cost.data_ptr(), _stream_ptr(dev)),
+                       "shw_sinkhorn_forward_train")
+        ctx.save_for_backward(xc, yc, ws)
+        ctx.cfg = (B, n, m, eps, max_iter, norm_p, cost_pow)
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xc, yc, ws = ctx.saved_tensors
+        B, n, m, eps, max_iter, norm_p, cost_pow = ctx.cfg
+        dev = xc.device
+        gx, gy = torch.empty_like(xc), torch.empty_like(yc)
+        gc = g.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.shw_sinkhorn_backward(xc.data_ptr(), yc.data_ptr(), B, n, m, eps, max_iter, norm_p, cost_pow,
+                                                 ws.data_ptr(), gc.data_ptr(), gx.data_ptr(), gy.data_ptr(),
+                                                 _stream_ptr(dev)), "shw_sinkhorn_backward")
+        return gx, gy, None, None, None, None, None
+
+
 def sinkhorn_pair_costs(x, y, eps, max_iter, norm_p=2, cost_pow=1, thresh=1e-9, return_plan=False):
     """(B,n,3), (B,m,3) -> (B,) transport costs sum_ij P_ij C_ij [, P, C]."""
     _check_cloud("x", x)
     _check_cloud("y", y)
     if x.dim() != 3 or y.dim() != 3 or x.shape[0] != y.shape[0]:
         raise ValueError("x and y must be (B,n,3) and (B,m,3) with the same B")
-    if x.requires_grad or y.requires_grad:
-        raise NotImplementedError("the HIP Sinkhorn path is forward-only (no gradient through the iterations)")
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        cost = _SinkhornCosts.apply(x, y, float(eps), int(max_iter), int(norm_p), int(cost_pow), float(thresh))
+        P = C = None
+        if return_plan:                 # the dense outputs are plain tensors (no gradient flows through them here)
+            with torch.no_grad():
+                _, P, C = sinkhorn_pair_costs(x.detach(), y.detach(), eps, max_iter, norm_p, cost_pow, thresh, True)
+        return cost, P, C
     lib = _lib.load()
     B, n, _ = x.shape
     m = y.shape[1]

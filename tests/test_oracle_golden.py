@@ -299,3 +299,22 @@ def test_live_criterion_mirror_against_its_restatement(golden, mode):
     assert results[0][0] == results[1][0]
     for x, y in zip(results[0][1:], results[1][1:]):
         assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------- G7b: Sinkhorn gradients (the unrolled iterations)
+@pytest.mark.parametrize("tag,eps,iters,norm_p,cost_pow,red", [("eps0.05_it60", 0.05, 60, 2, 1, "sum"),
+                                                               ("eps0.1_it5", 0.1, 5, 2, 1, "mean"),
+                                                               ("L1_eps0.05_it30", 0.05, 30, 1, 1, "sum"),
+                                                               ("N2_eps0.05_it30", 0.05, 30, 2, 2, "mean")])
+def test_g7b_sinkhorn_restatement_autograd(golden, tag, eps, iters, norm_p, cost_pow, red):
+    from oracle import sinkhorn_mirror
+    g = golden("g7b_sinkhorn_grad.npz")
+    x, y = T(g["x"]).requires_grad_(True), T(g["y"]).requires_grad_(True)
+    cost = sinkhorn_mirror.sinkhorn_costs(x, y, eps, iters, norm_p=norm_p, cost_pow=cost_pow)[0]
+    if cost_pow != 1:
+        cost = cost.pow(1.0 / cost_pow)
+    total = cost.sum() if red == "sum" else cost.mean()
+    total.backward()
+    assert rel(total.detach().numpy(), g[f"cost_{tag}"]) < 2e-5
+    assert np.abs(x.grad.numpy() - g[f"gx_{tag}"]).max() < 1e-4 * np.abs(g[f"gx_{tag}"]).max()
+    assert np.abs(y.grad.numpy() - g[f"gy_{tag}"]).max() < 1e-4 * np.abs(g[f"gy_{tag}"]).max()

@@ -806,8 +806,10 @@ def test_g7_sinkhorn_variants_and_call_shapes(shw, golden):
     assert rel(n2(x, y, "cuda")[0].item(), g["cost_N2_mean"]) < 5e-4
     single = shw.log_Sinkhorn_Distance_Loss(0.05, 10)(x[0], y[0], "cuda")
     assert single[0].dim() == 0 and tuple(single[1].shape) == (96, 80)
-    with pytest.raises(NotImplementedError):
-        shw.log_Sinkhorn_Distance_Loss(0.05, 10)(x.clone().requires_grad_(True), y, "cuda")
+    # round 2: differentiable like the reference (gradient parity: tests/test_r2_gpu.py, fixture G7b)
+    xr = x.clone().requires_grad_(True)
+    shw.log_Sinkhorn_Distance_Loss(0.05, 10, batch_reduction="sum")(xr, y, "cuda")[0].backward()
+    assert torch.isfinite(xr.grad).all() and xr.grad.abs().max() > 0
 
 
 @pytest.mark.parametrize("n,m", [(1, 1), (5, 700), (300, 257), (1024, 1024)])
