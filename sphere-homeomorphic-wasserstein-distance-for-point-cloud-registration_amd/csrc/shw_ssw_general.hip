@@ -19,6 +19,13 @@
 // handful of terms per atom; their order, hence the last bit, may vary between runs).
 #include "ssw_common.hpp"
 
+#ifndef SHW_DBG_EXTRA_LDS
+#define SHW_DBG_EXTRA_LDS 0
+#endif
+#ifndef SHW_GENERAL_CHAINS
+#define SHW_GENERAL_CHAINS 2    // interleaved rank walks per lane in the weighted slope evaluation
+#endif
+
 namespace shw {
 
 struct GeneralArgs {
@@ -187,17 +194,135 @@ __device__ __forceinline__ void lower_bounds2_arr(const float* arr, int count, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Walking searches (round 2, weighted clouds).  A lane's atoms are CONSECUTIVE sorted atoms, so their CDF levels
+// ascend and so do their ranks in the other cloud's CDF: after one binary search for the lane's first atom the rank
+// of every further atom is found by WALKING forward from its predecessor's -- four entries are read at once and the
+// entries below the key counted; with weights of comparable size the walk advances ~1 entry per atom and one round
+// of four reads settles it (the rare lane that needs more loops, wave-uniformly; a walk longer than kWalkRounds
+// rounds falls back to the binary search).  The ranks are the binary search's, entry for entry: #{< key} is monotone
+// in the key.  12 + 4 probes per atom become 4 + 3, and the chain of dependent reads per evaluation 32 instead
+// of 4 x 15.  `prev` (the previous key) detects the one place where the keys of a lane do not ascend -- the rotated
+// target's wrap from level ~1 to level ~0 -- and restarts the walk at entry 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWalkRounds = 6;
+// Window reads at constant offsets: an array in lds_slot layout ([r][lane], entry i at row i % EPT, column i / EPT)
+// keeps entries i, i+1, ... of one column one row (256 bytes) apart -- until the column ends.  kWalkExt extra rows
+// under the array repeat the first kWalkExt rows one column to the left (ext[r][c] = arr[r - EPT][c + 1], +inf past the
+// last column), so that the kWalkExt entries from ANY index are base + q * 256 bytes: one address, kWalkExt reads.
+constexpr int kWalkExt = 6;
+
+template <int EPT>
+__device__ __forceinline__ void fill_walk_ext(float* arr, int lane) {
+#pragma unroll
+  for (int q = 0; q < kWalkExt; ++q) {
+    const float x = arr[q * kWave + min(lane + 1, kWave - 1)];
+    arr[(EPT + q) * kWave + lane] = lane + 1 < kWave ? x : __builtin_inff();
+  }
+}
+
+template <int EPT>
+__device__ __forceinline__ int upper_bound_arr(const float* arr, int count, float key) {
+  constexpr int P = EPT * kWave;
+  int le = 0;
+#pragma unroll
+  for (int st = P / 2; st >= 1; st >>= 1) {
+    const float x = arr[lds_slot<EPT>(le + st - 1)];
+    le += ((le + st - 1 < count) && (x <= key)) ? st : 0;
+  }
+  const float x = arr[lds_slot<EPT>(min(le, P - 1))];
+  return le + (((le < count) && (x <= key)) ? 1 : 0);
+}
+
+template <int EPT>
+__device__ __forceinline__ int lower_bound_arr(const float* arr, int count, float key) {
+  constexpr int P = EPT * kWave;
+  int lt = 0;
+#pragma unroll
+  for (int st = P / 2; st >= 1; st >>= 1) {
+    const float x = arr[lds_slot<EPT>(lt + st - 1)];
+    lt += ((lt + st - 1 < count) && (x < key)) ? st : 0;
+  }
+  const float x = arr[lds_slot<EPT>(min(lt, P - 1))];
+  return lt + (((lt < count) && (x < key)) ? 1 : 0);
+}
+
+// #{entries < key} for ONE key common to the wave: two rounds of 64 probes instead of 12 dependent ones
+template <int EPT>
+__device__ __forceinline__ int wave_lower_bound_arr(const float* arr, int count, float key, int lane) {
+  static_assert(EPT <= kWave, "one probe per lane covers a block of EPT entries");
+  const int i1 = lane * EPT + EPT - 1;                       // last entry of block `lane`
+  const bool b1 = (i1 < count) && (arr[lds_slot<EPT>(i1)] < key);
+  const int blk = __builtin_popcountll(__builtin_amdgcn_ballot_w64(b1));   // blocks entirely below the key
+  const int i2 = min(blk, kWave - 1) * EPT + min(lane, EPT - 1);
+  const bool b2 = (blk < kWave) && (lane < EPT) && (i2 < count) && (arr[lds_slot<EPT>(i2)] < key);
+  return blk * EPT + __builtin_popcountll(__builtin_amdgcn_ballot_w64(b2));
+}
+
+// ranks of NA keys that ascend (except where key < prev: restart).  ptr: in, a rank not above key[0]'s unless the
+// keys restart; out, the rank of the last key.  Dead keys (live[a] false) are not searched: they take the running rank.
+template <int EPT, int NA>
+__device__ __forceinline__ void walk_lower_bounds2(const float* arr, int count, const float (&key)[NA],
+                                                   const bool (&live)[NA], float& prev, int& ptr, int (&lt)[NA],
+                                                   int (&le)[NA]) {
+  constexpr int P = EPT * kWave;
+  bool again = false;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const float k = live[a] ? key[a] : prev;
+    ptr = k < prev ? 0 : ptr;
+    prev = k;
+    int rounds = 0;
+    for (;;) {
+      float x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] = arr[lds_slot<EPT>(min(ptr + q, P - 1))];
+      int adv = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) adv += ((ptr + q < count) && (x[q] < k)) ? 1 : 0;
+      ptr += adv;
+      if (__builtin_amdgcn_ballot_w64(adv == 4) == 0) break;
+      if (++rounds >= kWalkRounds) { ptr = lower_bound_arr<EPT>(arr, count, k); break; }
+    }
+    lt[a] = ptr;
+    const float e0 = arr[lds_slot<EPT>(min(ptr, P - 1))];
+    const float e1 = arr[lds_slot<EPT>(min(ptr + 1, P - 1))];
+    const float e2 = arr[lds_slot<EPT>(min(ptr + 2, P - 1))];
+    const bool q0 = (ptr < count) && (e0 == k);
+    const bool q1 = q0 && (ptr + 1 < count) && (e1 == k);
+    const bool q2 = q1 && (ptr + 2 < count) && (e2 == k);
+    le[a] = ptr + (q0 ? 1 : 0) + (q1 ? 1 : 0);
+    again |= q2;
+  }
+  if (again) {                                               // three or more equal entries: degenerate weights
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const float k = live[a] ? key[a] : prev;
+      int pos = 0;
+#pragma unroll
+      for (int st = P / 2; st >= 1; st >>= 1) {
+        const float y = arr[lds_slot<EPT>(pos + st - 1)];
+        pos += ((pos + st - 1 < count) && (y <= k)) ? st : 0;
+      }
+      const float y = arr[lds_slot<EPT>(min(pos, P - 1))];
+      le[a] = live[a] ? pos + (((pos < count) && (y <= k)) ? 1 : 0) : le[a];
+    }
+  }
+}
+
 // the target after moving mass theta around the circle (reference :31-48, evaluated lazily)
 template <int EPT, bool UNIFORM = false>
 struct Rotated {
   Side<EPT, UNIFORM> t;
   float turns, frac;
   int start;                               // number of wrapped atoms = first atom of the rotated order
-  __device__ __forceinline__ void set(const Side<EPT, UNIFORM>& target, float theta) {
+  __device__ __forceinline__ void set(const Side<EPT, UNIFORM>& target, float theta, int lane) {
     t = target;
     turns = floorf(theta);
     frac = theta - turns;
-    start = target.below(frac, true);      // (cdf - frac) < 0  <=>  cdf < frac
+    // (cdf - frac) < 0  <=>  cdf < frac
+    if constexpr (UNIFORM) start = target.below(frac, true);
+    else start = wave_lower_bound_arr<EPT>(target.cdf, target.count, frac, lane);
     if (start >= target.count) start = 0;  // degenerate (no atom left unwrapped): argmin over all-inf = 0
   }
   // atom j of the sorted target: shifted CDF and position unrolled onto the real line
@@ -243,6 +368,34 @@ struct Rotated {
     }
     return lo;
   }
+  // the same for NB ASCENDING keys by a forward walk over the rotated entries (see walk_lower_bounds2; no restart:
+  // the keys are source levels).  cnt_io: in, a count not above key[0]'s; out, the count of the last key.
+  template <int NB>
+  __device__ __forceinline__ void below_walk(const float (&key)[NB], int& cnt_io, int (&cnt)[NB]) const {
+    const int m = t.count;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      int rounds = 0;
+      for (;;) {
+        float x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = cdf_at(min(cnt_io + q, m - 1));
+        int adv = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) adv += ((cnt_io + q < m) && (x[q] < key[b])) ? 1 : 0;
+        cnt_io += adv;
+        if (__builtin_amdgcn_ballot_w64(adv == 4) == 0) break;
+        if (++rounds >= kWalkRounds) {
+          const float k1[1] = {key[b]};
+          int c1[1];
+          below_batch<1>(k1, c1);
+          cnt_io = c1[0];
+          break;
+        }
+      }
+      cnt[b] = cnt_io;
+    }
+  }
   // the same for NB keys at once, fixed trip count (see lower_bounds2)
   template <int NB>
   __device__ __forceinline__ void below_batch(const float (&key)[NB], int (&cnt)[NB]) const {
@@ -285,11 +438,19 @@ template <int EPT, int PMODE, bool UNIFORM>
 __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, float p, int p_int,
                            float& d_plus, float& d_minus) {
   Rotated<EPT, UNIFORM> R;
-  R.set(T, theta);
+  R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   float sp = 0.f, sm = 0.f;
   constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
   constexpr int NA = EPT < NA_MAX ? EPT : NA_MAX;
+  int walk_ptr = 0;                                          // weighted: rank of the lane's previous atom
+  float walk_prev = 0.f;
+  if constexpr (!UNIFORM) {
+    float c0, p0;
+    R.atom(min(lane * EPT, m - 1), c0, p0);
+    walk_ptr = lower_bound_arr<EPT>(S.cdf, n, c0);
+    walk_prev = c0;
+  }
 #pragma nounroll
   for (int r0 = 0; r0 < EPT; r0 += NA) {
     // NA + 1 consecutive atoms: atom a and its successor a + 1 (the atom after the last one is atom 0; indices
@@ -310,7 +471,14 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
       npos[a] = wp[a + 1] + ((wj[a + 1] == R.start) ? 1.f : 0.f);   // successor of the last rotated atom: first + 1
     }
     int lt[NA], le[NA];
-    lower_bounds2<EPT, UNIFORM, NA>(S, cdf, lt, le);
+    if constexpr (UNIFORM) {
+      lower_bounds2<EPT, UNIFORM, NA>(S, cdf, lt, le);
+    } else {
+      bool alive[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) alive[a] = (lane * EPT + r0 + a) < m;
+      walk_lower_bounds2<EPT, NA>(S.cdf, n, cdf, alive, walk_prev, walk_ptr, lt, le);
+    }
     const float v0 = S.v(0);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
@@ -330,17 +498,153 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
   d_minus = wave_sum_uniform(sm, lane);
 }
 
+// cut_slopes for weighted clouds as C interleaved walks (see walk_lower_bounds2): chain c covers atoms
+// [c * EPT/C, (c+1) * EPT/C) of the lane, the C chains advance together -- 4 C independent reads per round, EPT/C
+// rounds per evaluation -- and each chain's first rank is carried from one evaluation of the solve to the next
+// (`anchor`; warm = false: binary search): the cut moves by less than a level spacing between late evaluations, so
+// the carried rank is put right by one backward and one forward round instead of a 12-probe search.
+template <int EPT, int PMODE, int C>
+__device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false>& T, float theta, int lane, float p,
+                                int p_int, float& d_plus, float& d_minus, int (&anchor)[C], bool warm) {
+  constexpr int P = EPT * kWave;
+  constexpr int LEN = EPT / C;
+  static_assert(EPT % C == 0, "chains of equal length");
+  Rotated<EPT, false> R;
+  R.set(T, theta, lane);
+  const int n = S.count, m = T.count;
+  const float* arr = S.cdf;
+  auto atom_q = [&](int q, float& c, float& ps, int& j) {    // atom q of the lane's run; q == m: atom 0, past it: the last
+    j = q < m ? q : (q == m ? 0 : m - 1);
+    R.atom(j, c, ps);
+  };
+  int ptr[C];
+  float prev[C], own_c[C], own_p[C];
+  // ---- first ranks
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    int j;
+    atom_q(lane * EPT + c * LEN, own_c[c], own_p[c], j);
+    prev[c] = own_c[c];
+    ptr[c] = min(max(anchor[c], 0), n);
+  }
+  if (warm) {                                                // backwards until the entry before ptr is below the key
+    int rounds = 0;
+    for (;;) {
+      bool more = false;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        int back = 0;
+        bool run = true;
+#pragma unroll
+        for (int q = 1; q <= 4; ++q) {
+          const float x = arr[lds_slot<EPT>(max(ptr[c] - q, 0))];
+          run = run && (ptr[c] - q >= 0) && !(x < prev[c]);
+          back += run ? 1 : 0;
+        }
+        ptr[c] -= back;
+        more |= back == 4;
+      }
+      if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+      if (++rounds >= kWalkRounds) { warm = false; break; }
+    }
+  }
+  if (!warm) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) ptr[c] = lower_bound_arr<EPT>(arr, n, prev[c]);
+  }
+  float sp = 0.f, sm = 0.f;
+  const float v0 = S.v(0);
+#pragma nounroll
+  for (int i = 0; i < LEN; ++i) {
+    float k[C], pos[C], npos[C];
+    bool live[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int q = lane * EPT + c * LEN + i;
+      live[c] = q < m;
+      pos[c] = own_p[c];
+      k[c] = live[c] ? own_c[c] : prev[c];
+      int nj;
+      atom_q(q + 1, own_c[c], own_p[c], nj);                 // the successor: the chain's own atom of the next round
+      npos[c] = own_p[c] + ((nj == R.start) ? 1.f : 0.f);    // successor of the last rotated atom: first + 1
+      ptr[c] = k[c] < prev[c] ? 0 : ptr[c];                  // the wrap: levels restart at ~0
+      prev[c] = k[c];
+    }
+    // ranks #{< k} (ptr) and #{<= k} (le): count both among the kWalkExt entries from ptr on (dead entries are +inf);
+    // settled unless all of them are <= k
+    int rounds = 0;
+    int le[C];
+    for (;;) {
+      bool more = false;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float* w = arr + lds_slot<EPT>(min(ptr[c], P - 1));
+        int lta = 0, lea = 0;
+#pragma unroll
+        for (int q = 0; q < kWalkExt; ++q) {
+          const float x = w[q * kWave];
+          lta += (x < k[c]) ? 1 : 0;
+          lea += (x <= k[c]) ? 1 : 0;
+        }
+        const bool inside = ptr[c] < P;                      // ptr == P (every entry below the key): nothing to read
+        lta = inside ? lta : 0;
+        lea = inside ? lea : 0;
+        le[c] = ptr[c] + lea;
+        ptr[c] += lta;
+        more |= lea == kWalkExt;
+      }
+      if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+      if (++rounds >= kWalkRounds) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          ptr[c] = lower_bound_arr<EPT>(arr, n, k[c]);
+          le[c] = upper_bound_arr<EPT>(arr, n, k[c]);
+        }
+        break;
+      }
+    }
+    if (i == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) anchor[c] = ptr[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float al = S.v(min(ptr[c], n - 1));              // left-continuous source quantile (:50-51)
+      const float sv = S.v(min(le[c], n - 1));               // right-continuous on the extended arrays (:54-57)
+      const float ar = le[c] < n ? sv : v0 + 1.f;
+      const float tp = powp<PMODE>(al - npos[c], p, p_int) - powp<PMODE>(al - pos[c], p, p_int);
+      const float tm = powp<PMODE>(ar - npos[c], p, p_int) - powp<PMODE>(ar - pos[c], p, p_int);
+      sp += live[c] ? tp : 0.f;
+      sm += live[c] ? tm : 0.f;
+    }
+  }
+  d_plus = wave_sum_uniform(sp, lane);
+  d_minus = wave_sum_uniform(sm, lane);
+}
+
 // transport cost at a fixed cut (reference Cost, :94-112).  GRAD: also accumulates
 // d cost / d (sorted source atom) into gs and d cost / d (sorted target atom) into gt.
 template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
 __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, float p, int p_int,
                           float* gs, float* gt) {
   Rotated<EPT, UNIFORM> R;
-  R.set(T, theta);
+  R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   float acc = 0.f;
   constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
   constexpr int NA = EPT < NA_MAX ? EPT : NA_MAX;
+  int walk_cnt = 0, walk_ptr = 0;                            // weighted: ranks of the lane's previous atoms
+  float walk_prev = 0.f;
+  if constexpr (!UNIFORM) {
+    const float k1[1] = {S.c(min(lane * EPT, n - 1))};
+    int c1[1];
+    R.template below_batch<1>(k1, c1);
+    walk_cnt = c1[0];
+    float c0, p0;
+    R.atom(min(lane * EPT, m - 1), c0, p0);
+    walk_ptr = lower_bound_arr<EPT>(S.cdf, n, c0);
+    walk_prev = c0;
+  }
 #pragma nounroll
   for (int r0 = 0; r0 < EPT; r0 += NA) {
     {  // grid points = source CDF levels A_e
@@ -348,7 +652,8 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
       int cnt[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) g[a] = S.c(min(lane * EPT + r0 + a, n - 1));
-      R.template below_batch<NA>(g, cnt);                    // rotated target atom active at g
+      if constexpr (UNIFORM) R.template below_batch<NA>(g, cnt);   // rotated target atom active at g
+      else R.template below_walk<NA>(g, walk_cnt, cnt);
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
         const int e = lane * EPT + r0 + a;
@@ -375,7 +680,14 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
       int lt[NA], le[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) R.atom(min(lane * EPT + r0 + a, m - 1), g[a], b[a]);
-      lower_bounds2<EPT, UNIFORM, NA>(S, g, lt, le);
+      if constexpr (UNIFORM) {
+        lower_bounds2<EPT, UNIFORM, NA>(S, g, lt, le);
+      } else {
+        bool alive[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) alive[a] = true;        // (indices past the end repeat the last atom: keys ascend)
+        walk_lower_bounds2<EPT, NA>(S.cdf, n, g, alive, walk_prev, walk_ptr, lt, le);
+      }
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
         const int e = lane * EPT + r0 + a;
@@ -463,7 +775,7 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {                        // sorted position lane*EPT + r -> slot r*64 + lane
         dval[r * kWave + lane] = val[r];
-        dcdf[r * kWave + lane] = w[r];
+        dcdf[r * kWave + lane] = (lane * EPT + r < count) ? w[r] : __builtin_inff();   // (window reads count on it)
       }
     }
     if (which == 0) mean_t = mean; else mean_s = mean;
@@ -520,6 +832,12 @@ __device__ __forceinline__ void prepare_from_indices(const GeneralArgs& G, int s
   }
 }
 
+// weighted clouds with >= 8 atoms per lane evaluate their slopes by walking (cut_slopes_walk)
+template <int EPT, bool UNIFORM>
+constexpr bool general_walks() { return !UNIFORM && EPT >= 8; }
+template <int EPT, bool UNIFORM>
+constexpr int general_ext_floats() { return general_walks<EPT, UNIFORM>() ? kWalkExt * kWave : 0; }
+
 template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
 __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -530,11 +848,12 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   // source gradient row), target gradient row (GRAD only)
   float* s_val = lds;
   float* t_val = lds + ROW;
+  constexpr int EXT = general_ext_floats<EPT, UNIFORM>();     // window rows under the source CDF (fill_walk_ext)
   float* s_cdf = UNIFORM ? nullptr : lds + 2 * ROW;
-  float* t_cdf = UNIFORM ? nullptr : lds + 3 * ROW;
+  float* t_cdf = UNIFORM ? nullptr : lds + 3 * ROW + EXT;
   // (loss only: the coordinates-by-original-index row of the sort shares the source row -- the gather out of it
   //  is complete before the sorted values are written, LDS operations of a wave execute in order)
-  float* scratch = GRAD ? lds + (UNIFORM ? 2 : 4) * ROW : s_val;
+  float* scratch = GRAD ? lds + (UNIFORM ? 2 : 4) * ROW + EXT : s_val;
   float* gt = scratch + ROW;                                 // GRAD only
 
   const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
@@ -561,6 +880,10 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   }
 
   Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
+  if constexpr (general_walks<EPT, UNIFORM>()) {
+    fill_walk_ext<EPT>(s_cdf, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
 
   // ---- the cut: minimiser of the convex, piecewise LINEAR cost over theta in [-1, 1] -------------------
   // The reference bisects [-1, 1] from theta = 0 on the sign of dCost until the bracket is below eps/L = 1e-7,
@@ -573,6 +896,9 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   // spacing (G.min_width: half a level of the lcm grid without weights, the reference's 1e-7 with weights) it
   // holds at most one kink and the tangent intersection IS the minimiser.
   float t_mid = 0.f;
+#ifdef SHW_DBG_EVALS
+  int dbg_evals = 0, dbg_bracket_at = -1;
+#endif
   if (G.cut_given) {
     t_mid = G.idx_handoff ? handed_cut : G.cut_scratch[(long)s * G.cut_stride];   // solved by the launch just before
   } else {
@@ -581,13 +907,43 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     if (!(t_mid >= -1.f)) t_mid = 0.f;                         // non-finite input
     bool lo_tight = false, hi_tight = false;
     float step = G.first_step, dp_lo = 0.f, dm_hi = 0.f;
-    for (int it = 0; it < 64; ++it) {                          // <= ~25 doublings + ~25 halvings
+    float f_lo = 0.f, f_hi = 0.f, t_prev = 0.f, f_prev = 0.f;  // secant state (weighted clouds)
+    constexpr int kChains = EPT >= SHW_GENERAL_CHAINS ? SHW_GENERAL_CHAINS : EPT;
+    int anchors[kChains] = {};                                 // first ranks of the previous evaluation (cut_slopes_walk)
+    int last_side = 0, secant_steps = 0;
+    bool have_prev = false;
+#ifndef SHW_DBG_MAX_EVALS
+#define SHW_DBG_MAX_EVALS 96
+#endif
+    for (int it = 0; it < SHW_DBG_MAX_EVALS; ++it) {
+#ifdef SHW_DBG_EVALS
+      dbg_evals = it + 1;
+      if (dbg_bracket_at < 0 && lo_tight && hi_tight) dbg_bracket_at = it;
+#endif                          // <= ~25 doublings + ~25 halvings
       float dp, dm;
-      cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
+      if constexpr (!general_walks<EPT, UNIFORM>()) {
+        cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
+      } else {
+        cut_slopes_walk<EPT, PMODE, kChains>(S, T, t_mid, lane, A.p, A.p_int, dp, dm, anchors, it > 0);
+      }
       if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece (:186-187)
       if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
       if (dp < 0.f) { t_lo = t_mid; lo_tight = true; dp_lo = dp; }
       else { t_hi = t_mid; hi_tight = true; dm_hi = dm; }
+      if constexpr (!UNIFORM) {
+        // weighted clouds: by convexity an end of the bracket is within  width * |slope at that end|  of the minimum
+        // COST.  Below kGain (1e-12: costs are O(1e-2), fp32 resolves 1e-9 of that) nothing is left to gain and the
+        // end is the answer -- with ~n*m micro-kinks the slopes near the optimum are ~1e-6 and this ends the search
+        // a few halvings before eps/L, and without the three cost evaluations of the reference's finish, which
+        // resolve nothing at that scale.  Coinciding levels (equal weights given explicitly: few, large kinks) keep
+        // large slopes on both sides and take the reference's exit below.
+        constexpr float kGain = 1e-12f;
+        if (lo_tight && hi_tight) {
+          const float w = t_hi - t_lo;
+          const float g_lo = -w * dp_lo, g_hi = w * dm_hi;
+          if (fminf(g_lo, g_hi) < kGain) { t_mid = g_lo < g_hi ? t_lo : t_hi; break; }
+        }
+      }
       if ((t_hi - t_lo) < G.min_width) {                       // :189-200
         float unused;
         if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, unused);
@@ -613,7 +969,41 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
         if (c_hi < best) { best = c_hi; t_mid = t_hi; }
         break;
       }
-      if (lo_tight && hi_tight) {
+      if constexpr (!UNIFORM) {
+        // Weighted clouds (round 2).  The cost has n*m kinks (every coincidence of a source level with a target
+        // level), ~2.4e-7 apart at 2048 points: its one-sided slope is, at every scale above that, a smooth increasing
+        // function -- exactly linear for p = 2 with the masses fixed.  Halving the bracket down to eps/L = 1e-7 as
+        // the reference does takes ~17 evaluations after ~6 doublings; a secant on the slope gets there in 3-5:
+        //   * no bracket yet: the line through the last two evaluations, over-stepped by a quarter (at least `step`);
+        //   * bracket: regula falsi with the Illinois rule (an end that stays put twice has its slope halved, which
+        //     throws the next point across the root) so that BOTH ends close in; the midpoint when the secant point
+        //     is not strictly inside, and plain halving after kSecant steps.
+        // The exit (width < eps/L, then the reference's tangent intersection) is unchanged.
+        constexpr int kSecant = 24;
+        const float f = dp < 0.f ? dp : dm;
+        const int side = dp < 0.f ? -1 : 1;
+        if (side < 0) { f_lo = f; if (last_side < 0 && hi_tight) f_hi *= 0.5f; }
+        else { f_hi = f; if (last_side > 0 && lo_tight) f_lo *= 0.5f; }
+        float t_next;
+        if (lo_tight && hi_tight) {
+          const float w = t_hi - t_lo;
+          t_next = t_lo + w * (-f_lo) / (f_hi - f_lo);
+          if (!(t_next > t_lo && t_next < t_hi) || ++secant_steps > kSecant) t_next = t_lo + 0.5f * w;
+        } else {
+          // p = 2: the cost is ~quadratic in the cut with curvature ~2 for clouds spread around the circle
+          if (PMODE == 2 && !have_prev) step = fmaxf(step, 0.5f * fabsf(f));
+          t_next = t_mid - (float)side * step;
+          if (have_prev && (f - f_prev) * (t_mid - t_prev) > 0.f) {
+            const float root = t_mid - f * (t_mid - t_prev) / (f - f_prev);
+            const float over = t_mid + 1.25f * (root - t_mid);
+            t_next = side < 0 ? fmaxf(t_next, over) : fminf(t_next, over);
+          }
+          t_next = fminf(fmaxf(t_next, t_lo), t_hi);
+          step *= 2.f;
+        }
+        t_prev = t_mid; f_prev = f; have_prev = true; last_side = side;
+        t_mid = t_next;
+      } else if (lo_tight && hi_tight) {
         t_mid = (t_lo + t_hi) * 0.5f;
       } else if (dp < 0.f) {
         t_mid = fminf(t_lo + step, t_hi);
@@ -639,6 +1029,9 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   if (lane == 0) {
     A.slice_cost[s] = cost;
     if (G.slice_theta) G.slice_theta[s] = t_mid;
+#ifdef SHW_DBG_EVALS                                          // developer aid: evaluations + 100 * (evaluations before the bracket)
+    if (G.slice_theta && !G.cut_given) G.slice_theta[s] = (float)(dbg_evals + 100 * (dbg_bracket_at < 0 ? 0 : dbg_bracket_at));
+#endif
   }
   if constexpr (GRAD) {
     __builtin_amdgcn_wave_barrier();
@@ -818,7 +1211,8 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   const bool uniform = G.wu == nullptr && G.wv == nullptr;   // no weights: CDFs in closed form, no searches
 #define SHW_LAUNCH_GENERAL(PM, GR, ARGS)                                                                       \
   do {                                                                                                         \
-    const size_t lds_ = (size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave * sizeof(float);            \
+    const size_t lds_ = ((size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave +                          \
+                         (uniform ? 0 : general_ext_floats<EPT, false>())) * sizeof(float) + SHW_DBG_EXTRA_LDS; \
     if (uniform) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, true>), grid, block, lds_, stream, ARGS); \
     else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, false>), grid, block, lds_, stream, ARGS);        \
   } while (0)
