@@ -17,6 +17,7 @@
 // source / target density" option (train_W_COS.py:292-293,334-336) and the u_weights / v_weights
 // arguments (:289) land here.  Gradients are accumulated per sorted atom with LDS float atomics (a
 // handful of terms per atom; their order, hence the last bit, may vary between runs).
+#include "bin_sort_idx.hpp"
 #include "ssw_common.hpp"
 
 #ifndef SHW_DBG_EXTRA_LDS
@@ -257,6 +258,46 @@ __device__ __forceinline__ int wave_lower_bound_arr(const float* arr, int count,
   const int i2 = min(blk, kWave - 1) * EPT + min(lane, EPT - 1);
   const bool b2 = (blk < kWave) && (lane < EPT) && (i2 < count) && (arr[lds_slot<EPT>(i2)] < key);
   return blk * EPT + __builtin_popcountll(__builtin_amdgcn_ballot_w64(b2));
+}
+
+// ranks #{< k} (ptr, updated) and #{<= k} (le) of C ascending key chains in `arr` (lds_slot layout with the
+// fill_walk_ext rows, dead entries +inf), each from its chain's previous rank on: both are counted among the kWalkExt
+// entries from ptr on and are settled unless all of those are <= k (then another round, wave-uniformly; binary
+// searches after kWalkRounds rounds).
+template <int EPT, int C>
+__device__ __forceinline__ void walk_window(const float* arr, int count, const float (&k)[C], int (&ptr)[C],
+                                            int (&le)[C]) {
+  constexpr int P = EPT * kWave;
+  int rounds = 0;
+  for (;;) {
+    bool more = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* w = arr + lds_slot<EPT>(min(ptr[c], P - 1));
+      int lta = 0, lea = 0;
+#pragma unroll
+      for (int q = 0; q < kWalkExt; ++q) {
+        const float x = w[q * kWave];
+        lta += (x < k[c]) ? 1 : 0;
+        lea += (x <= k[c]) ? 1 : 0;
+      }
+      const bool inside = ptr[c] < P;                        // ptr == P (every entry below the key): nothing to read
+      lta = inside ? lta : 0;
+      lea = inside ? lea : 0;
+      le[c] = ptr[c] + lea;
+      ptr[c] += lta;
+      more |= lea == kWalkExt;
+    }
+    if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+    if (++rounds >= kWalkRounds) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        ptr[c] = lower_bound_arr<EPT>(arr, count, k[c]);
+        le[c] = upper_bound_arr<EPT>(arr, count, k[c]);
+      }
+      break;
+    }
+  }
 }
 
 // ranks of NA keys that ascend (except where key < prev: restart).  ptr: in, a rank not above key[0]'s unless the
@@ -505,7 +546,8 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
 // the carried rank is put right by one backward and one forward round instead of a 12-probe search.
 template <int EPT, int PMODE, int C>
 __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false>& T, float theta, int lane, float p,
-                                int p_int, float& d_plus, float& d_minus, int (&anchor)[C], bool warm) {
+                                int p_int, float& d_plus, float& d_minus, int (&anchor)[C], bool warm,
+                                float& cost_scale) {
   constexpr int P = EPT * kWave;
   constexpr int LEN = EPT / C;
   static_assert(EPT % C == 0, "chains of equal length");
@@ -518,7 +560,7 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
     R.atom(j, c, ps);
   };
   int ptr[C];
-  float prev[C], own_c[C], own_p[C];
+  float prev[C], own_c[C], own_p[C], mass[C];
   // ---- first ranks
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -526,6 +568,10 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
     atom_q(lane * EPT + c * LEN, own_c[c], own_p[c], j);
     prev[c] = own_c[c];
     ptr[c] = min(max(anchor[c], 0), n);
+    float bc, bp;                                            // mass of the chain's first atom: level step from its predecessor
+    R.atom(j > 0 ? j - 1 : m - 1, bc, bp);
+    mass[c] = own_c[c] - bc;
+    mass[c] += mass[c] < 0.f ? 1.f : 0.f;
   }
   if (warm) {                                                // backwards until the entry before ptr is below the key
     int rounds = 0;
@@ -552,11 +598,11 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
 #pragma unroll
     for (int c = 0; c < C; ++c) ptr[c] = lower_bound_arr<EPT>(arr, n, prev[c]);
   }
-  float sp = 0.f, sm = 0.f;
+  float sp = 0.f, sm = 0.f, sc = 0.f;
   const float v0 = S.v(0);
 #pragma nounroll
   for (int i = 0; i < LEN; ++i) {
-    float k[C], pos[C], npos[C];
+    float k[C], pos[C], npos[C], w[C];
     bool live[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -564,45 +610,18 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
       live[c] = q < m;
       pos[c] = own_p[c];
       k[c] = live[c] ? own_c[c] : prev[c];
+      w[c] = mass[c];
+      const float before = own_c[c];
       int nj;
       atom_q(q + 1, own_c[c], own_p[c], nj);                 // the successor: the chain's own atom of the next round
+      mass[c] = own_c[c] - before;                           // levels are rotated by a common shift: steps survive, mod 1
+      mass[c] += mass[c] < 0.f ? 1.f : 0.f;
       npos[c] = own_p[c] + ((nj == R.start) ? 1.f : 0.f);    // successor of the last rotated atom: first + 1
       ptr[c] = k[c] < prev[c] ? 0 : ptr[c];                  // the wrap: levels restart at ~0
       prev[c] = k[c];
     }
-    // ranks #{< k} (ptr) and #{<= k} (le): count both among the kWalkExt entries from ptr on (dead entries are +inf);
-    // settled unless all of them are <= k
-    int rounds = 0;
     int le[C];
-    for (;;) {
-      bool more = false;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float* w = arr + lds_slot<EPT>(min(ptr[c], P - 1));
-        int lta = 0, lea = 0;
-#pragma unroll
-        for (int q = 0; q < kWalkExt; ++q) {
-          const float x = w[q * kWave];
-          lta += (x < k[c]) ? 1 : 0;
-          lea += (x <= k[c]) ? 1 : 0;
-        }
-        const bool inside = ptr[c] < P;                      // ptr == P (every entry below the key): nothing to read
-        lta = inside ? lta : 0;
-        lea = inside ? lea : 0;
-        le[c] = ptr[c] + lea;
-        ptr[c] += lta;
-        more |= lea == kWalkExt;
-      }
-      if (__builtin_amdgcn_ballot_w64(more) == 0) break;
-      if (++rounds >= kWalkRounds) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          ptr[c] = lower_bound_arr<EPT>(arr, n, k[c]);
-          le[c] = upper_bound_arr<EPT>(arr, n, k[c]);
-        }
-        break;
-      }
-    }
+    walk_window<EPT, C>(arr, n, k, ptr, le);
     if (i == 0) {
 #pragma unroll
       for (int c = 0; c < C; ++c) anchor[c] = ptr[c];
@@ -616,10 +635,14 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
       const float tm = powp<PMODE>(ar - npos[c], p, p_int) - powp<PMODE>(ar - pos[c], p, p_int);
       sp += live[c] ? tp : 0.f;
       sm += live[c] ? tm : 0.f;
+      sc += live[c] ? w[c] * powp<PMODE>(al - pos[c], p, p_int) : 0.f;
     }
   }
   d_plus = wave_sum_uniform(sp, lane);
   d_minus = wave_sum_uniform(sm, lane);
+  // the cost with every target atom sent whole to the source quantile at its level: the size of the cost, for the
+  // solve's exit test
+  cost_scale = wave_sum_uniform(sc, lane);
 }
 
 // transport cost at a fixed cut (reference Cost, :94-112).  GRAD: also accumulates
@@ -737,7 +760,8 @@ __device__ __forceinline__ void sorted_cdf(float (&w)[EPT], int lane) {
 template <int EPT, bool UNIFORM = false>
 __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int lane, float* s_val, float* s_cdf,
                                               float* t_val, float* t_cdf, float* scratch, int (&sidx)[EPT],
-                                              int (&tidx)[EPT], float& mean_s, float& mean_t) {
+                                              int (&tidx)[EPT], float& mean_s, float& mean_t,
+                                              unsigned* counters = nullptr) {
   const SswArgs& A = G.base;
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n, m = A.m;
@@ -755,7 +779,12 @@ __device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int l
     asm volatile("" : "+v"(ln));
     float val[EPT];
     int idx[EPT];
-    const float part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
+    // weighted, >= 8 atoms per lane: the distribution sort of bin_sort_idx.hpp (32 EPT counters beside the staging
+    // row).  Without weights the kernel runs two waves per SIMD on 248 registers and the distribution sort's extra
+    // live words would spill (measured: 2.1 -> 3.3 ms at n = 2048, m = 1536): it keeps the network.
+    float part;
+    if constexpr (EPT >= 8 && !UNIFORM) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
+    else part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
     float mean = 0.f;                                        // mass-weighted mean coordinate (first guess of the cut)
     if constexpr (UNIFORM) {
       mean = wave_sum_uniform(part, lane) / (float)count;                                 // CDF = (i+1)/count in closed form: no array
@@ -866,7 +895,9 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     handed_cut = A.coef_t[(long)s * m + (m - 1)];            // read before the rows are reused
     prepare_from_indices<EPT>(G, s, lane, s_val, t_val, sidx, tidx);
   } else {
-    prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s, mean_t);
+    // sort counters (32 EPT words, weighted only): the source CDF row, which is written after both sorts' scatters
+    unsigned* counters = reinterpret_cast<unsigned*>(s_cdf);
+    prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s, mean_t, counters);
     if (!GRAD && G.idx_handoff) {                            // solve launch: leave the permutations for the gradient launch
       unsigned short* ps = reinterpret_cast<unsigned short*>(G.cut_scratch + (long)s * n);
       unsigned short* pt = reinterpret_cast<unsigned short*>(G.cut_scratch_t + (long)s * m);
@@ -910,6 +941,7 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     float f_lo = 0.f, f_hi = 0.f, t_prev = 0.f, f_prev = 0.f;  // secant state (weighted clouds)
     constexpr int kChains = EPT >= SHW_GENERAL_CHAINS ? SHW_GENERAL_CHAINS : EPT;
     int anchors[kChains] = {};                                 // first ranks of the previous evaluation (cut_slopes_walk)
+    float cost_scale = 0.f;                                    // size of the cost (cut_slopes_walk)
     int last_side = 0, secant_steps = 0;
     bool have_prev = false;
 #ifndef SHW_DBG_MAX_EVALS
@@ -924,20 +956,23 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
       if constexpr (!general_walks<EPT, UNIFORM>()) {
         cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
       } else {
-        cut_slopes_walk<EPT, PMODE, kChains>(S, T, t_mid, lane, A.p, A.p_int, dp, dm, anchors, it > 0);
+        cut_slopes_walk<EPT, PMODE, kChains>(S, T, t_mid, lane, A.p, A.p_int, dp, dm, anchors, it > 0, cost_scale);
       }
+#ifdef SHW_DBG_TRACE
+      if (s < 4 && lane == 0) printf("slice %d it %d t %.9f dp %.4e dm %.4e lo %.9f hi %.9f\n", s, it, t_mid, dp, dm, t_lo, t_hi);
+#endif
       if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece (:186-187)
       if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
       if (dp < 0.f) { t_lo = t_mid; lo_tight = true; dp_lo = dp; }
       else { t_hi = t_mid; hi_tight = true; dm_hi = dm; }
       if constexpr (!UNIFORM) {
         // weighted clouds: by convexity an end of the bracket is within  width * |slope at that end|  of the minimum
-        // COST.  Below kGain (1e-12: costs are O(1e-2), fp32 resolves 1e-9 of that) nothing is left to gain and the
-        // end is the answer -- with ~n*m micro-kinks the slopes near the optimum are ~1e-6 and this ends the search
-        // a few halvings before eps/L, and without the three cost evaluations of the reference's finish, which
-        // resolve nothing at that scale.  Coinciding levels (equal weights given explicitly: few, large kinks) keep
-        // large slopes on both sides and take the reference's exit below.
-        constexpr float kGain = 1e-12f;
+        // COST.  Below one fp32 ulp of the cost (and below 1e-12 in any case) nothing is left to gain and the end is the
+        // answer: with ~n*m micro-kinks the slope near the optimum is a noisy ~1e-6 and the search would spend its
+        // last evaluations inside that noise; this ends it a few halvings before eps/L, and without the three cost
+        // evaluations of the reference's finish, which resolve nothing at that scale.  Coinciding levels (equal
+        // weights given explicitly: few, large kinks) keep large slopes on both sides and take the reference's exit.
+        const float kGain = fmaxf(1e-12f, 1.2e-7f * cost_scale);
         if (lo_tight && hi_tight) {
           const float w = t_hi - t_lo;
           const float g_lo = -w * dp_lo, g_hi = w * dm_hi;
@@ -1193,6 +1228,187 @@ __global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// p == 1 with weights, >= 8 atoms per lane (round 2): the same formula as ssw_general_p1_kernel with
+//   * the two cross searches (target values below a source atom, source values not above a target atom) done by
+//     walking (walk_window: the lane's atoms ascend, so do their ranks in the other cloud's values);
+//   * levels and gaps of all 2 EPT atoms of the lane in REGISTERS: the median bisection reads no LDS (it was
+//     4 LDS reads per atom pair per step, ~40 steps per slice);
+//   * 6 rows of LDS instead of 8 (the two staging rows serve the source first, then the target): 3 slices per CU
+//     instead of 2;
+//   * coefficients un-permuted through LDS and stored coalesced.
+// ---------------------------------------------------------------------------------------------
+// levels and gaps of the atoms of one cloud (own) against the other (cross); SRC: own = source (rank = cross values
+// strictly below), else own = target (rank = cross values not above).  Rows lev_row / gap_row receive them at
+// [r][lane], dead atoms as (+inf, 0).  Returns the rank of the lane's first atom.
+template <int EPT, int C, bool SRC>
+__device__ __forceinline__ int p1_levels_walk(const Side<EPT>& O, const Side<EPT>& X, int lane, float* lev_row,
+                                              float* gap_row) {
+  constexpr int P = EPT * kWave;
+  constexpr int LEN = EPT / C;
+  const int no = O.count, nx = X.count;
+  const float inf = __builtin_inff();
+  int ptr[C];
+  float prev[C], own_v[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int e0 = lane * EPT + c * LEN;
+    own_v[c] = O.val[lds_slot<EPT>(min(e0, P - 1))];
+    prev[c] = O.val[lds_slot<EPT>(min(e0, no - 1))];
+    ptr[c] = lower_bound_arr<EPT>(X.val, nx, prev[c]);
+  }
+  int first_rank = 0;
+#pragma nounroll
+  for (int i = 0; i < LEN; ++i) {
+    float k[C], val[C], nxt_own[C];
+    bool live[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int e = lane * EPT + c * LEN + i;
+      live[c] = e < no;
+      val[c] = own_v[c];
+      own_v[c] = e + 1 < P ? O.val[lds_slot<EPT>(min(e + 1, P - 1))] : inf;   // dead values are +inf in the row
+      nxt_own[c] = own_v[c];
+      k[c] = live[c] ? val[c] : prev[c];
+      prev[c] = k[c];
+    }
+    int le[C];
+    walk_window<EPT, C>(X.val, nx, k, ptr, le);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int e = lane * EPT + c * LEN + i;
+      const int rank = SRC ? ptr[c] : le[c];
+      if (i == 0 && c == 0) first_rank = rank;
+      const float below = rank > 0 ? X.c(rank - 1) : 0.f;
+      const float mine = O.c(min(e, no - 1));
+      const float lev = SRC ? mine - below : below - mine;
+      const float cross = rank < nx ? X.v(min(rank, P - 1)) : inf;
+      const float nxt = fminf(nxt_own[c], cross);
+      const float gap = (nxt == inf ? 1.f : nxt) - val[c];
+      lev_row[(c * LEN + i) * kWave + lane] = live[c] ? lev : inf;
+      gap_row[(c * LEN + i) * kWave + lane] = live[c] ? gap : 0.f;
+    }
+  }
+  return first_rank;
+}
+
+template <int EPT, bool GRAD>
+__global__ __launch_bounds__(64) void ssw_general_p1_walk_kernel(GeneralArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ROW = EPT * kWave, EXT = kWalkExt * kWave;
+  constexpr int C = 2;
+  const SswArgs& A = G.base;
+  const int lane = threadIdx.x & 63;
+  float* s_val = lds;                                        // each value row with its window rows
+  float* t_val = s_val + ROW + EXT;
+  float* s_cdf = t_val + ROW + EXT;
+  float* t_cdf = s_cdf + ROW;
+  float* stage_a = t_cdf + ROW;                              // the sorts' scratch, then levels, then coefficients
+  float* stage_b = stage_a + ROW;                            // gaps, then coefficients
+
+  const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
+  if (s >= A.pairs * A.slices) return;
+  const int n = A.n, m = A.m;
+  int sidx[EPT], tidx[EPT];
+  float mean_s_unused = 0.f, mean_t_unused = 0.f;
+  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, stage_a, sidx, tidx, mean_s_unused, mean_t_unused,
+                     reinterpret_cast<unsigned*>(stage_b));
+  Side<EPT> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
+  fill_walk_ext<EPT>(s_val, lane);
+  fill_walk_ext<EPT>(t_val, lane);
+  __builtin_amdgcn_wave_barrier();
+
+  float lev_s[EPT], gap_s[EPT], lev_t[EPT], gap_t[EPT];
+  const int rank_s0 = p1_levels_walk<EPT, C, true>(S, T, lane, stage_a, stage_b);    // source atoms
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) { lev_s[r] = stage_a[r * kWave + lane]; gap_s[r] = stage_b[r * kWave + lane]; }
+  __builtin_amdgcn_wave_barrier();
+  const int rank_t0 = p1_levels_walk<EPT, C, false>(T, S, lane, stage_a, stage_b);   // target atoms
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) { lev_t[r] = stage_a[r * kWave + lane]; gap_t[r] = stage_b[r * kWave + lane]; }
+
+  const float inf = __builtin_inff();
+  float lo_lev = inf, hi_lev = -inf, total = 0.f;
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    lo_lev = fminf(lo_lev, fminf(lev_s[r], lev_t[r]));
+    hi_lev = fmaxf(hi_lev, fmaxf(lev_s[r] < inf ? lev_s[r] : -inf, lev_t[r] < inf ? lev_t[r] : -inf));
+    total += gap_s[r] + gap_t[r];
+  }
+  lo_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(-wave_max(-lo_lev, lane))));
+  hi_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(wave_max(hi_lev, lane))));
+  total = wave_sum_uniform(total, lane);
+
+  auto weight_below = [&](float t) -> float {               // sum of gaps of atoms with level <= t
+    float w = 0.f;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      w += (lev_s[r] <= t) ? gap_s[r] : 0.f;
+      w += (lev_t[r] <= t) ? gap_t[r] : 0.f;
+    }
+    return wave_sum_uniform(w, lane);
+  };
+  float med = lo_lev;
+  if (total >= 0.5f) {
+    float lo = lo_lev - 1.f, hi = hi_lev;                    // W(lo) = 0 < 0.5 <= W(hi) = total
+    for (int it = 0; it < 48 && lo < hi; ++it) {
+      const float mid = lo + (hi - lo) * 0.5f;
+      if (!(mid > lo && mid < hi)) break;                    // bracket exhausted at fp32 resolution
+      if (weight_below(mid) >= 0.5f) hi = mid; else lo = mid;
+    }
+    float best = inf;                                        // smallest level above the bracket's lower end
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      best = (lev_s[r] > lo) ? fminf(best, lev_s[r]) : best;
+      best = (lev_t[r] > lo) ? fminf(best, lev_t[r]) : best;
+    }
+    med = as_f(__builtin_amdgcn_readfirstlane(as_i(-wave_max(-best, lane))));
+  }
+
+  float acc = 0.f;
+  if constexpr (GRAD) __builtin_amdgcn_wave_barrier();       // the staging rows have been read: coefficients by index
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    if (e < n) {
+      const float here = fabsf(lev_s[r] - med);
+      acc += gap_s[r] * here;
+      if constexpr (GRAD) {
+        const float own = S.c(e) - (e > 0 ? S.c(e - 1) : 0.f);
+        const bool first = (e == 0) && (rank_s0 == 0);       // no target value below the first source atom
+        stage_a[sidx[r]] = (first ? 0.f : fabsf(lev_s[r] - own - med)) - here;
+      }
+    }
+    if (e < m) {
+      const float here = fabsf(lev_t[r] - med);
+      acc += gap_t[r] * here;
+      if constexpr (GRAD) {
+        const float own = T.c(e) - (e > 0 ? T.c(e - 1) : 0.f);
+        const bool first = (e == 0) && (rank_t0 == 0);       // no source value at or below the first target atom
+        stage_b[tidx[r]] = (first ? 0.f : fabsf(lev_t[r] + own - med)) - here;
+      }
+    }
+  }
+  const float cost = wave_sum_uniform(acc, lane);
+  if (lane == 0) {
+    A.slice_cost[s] = cost;
+    if (G.slice_theta) G.slice_theta[s] = med;
+  }
+  if constexpr (GRAD) {
+    __builtin_amdgcn_wave_barrier();
+    float* cs = A.coef_s + (long)s * n;
+    float* ct = A.coef_t + (long)s * m;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * kWave + lane;
+      if (i < n) cs[i] = stage_a[i];
+      if (i < m) ct[i] = stage_b[i];
+    }
+  }
+}
+
 template <int EPT>
 static int launch_general(GeneralArgs& G, hipStream_t stream) {
   SswArgs& A = G.base;
@@ -1202,10 +1418,16 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   const bool grad = A.coef_s != nullptr;
   const dim3 grid((unsigned)total), block(64);
   if (A.p == 1.f) {
-    const size_t lds1 = (size_t)8 * EPT * kWave * sizeof(float);
-    if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (grad) hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, true>), grid, block, lds1, stream, G);
-    else hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, false>), grid, block, lds1, stream, G);
+    if constexpr (EPT >= 8) {
+      const size_t lds1 = ((size_t)6 * EPT * kWave + 2 * kWalkExt * kWave) * sizeof(float);
+      if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
+      if (grad) hipLaunchKernelGGL((ssw_general_p1_walk_kernel<EPT, true>), grid, block, lds1, stream, G);
+      else hipLaunchKernelGGL((ssw_general_p1_walk_kernel<EPT, false>), grid, block, lds1, stream, G);
+    } else {
+      const size_t lds1 = (size_t)8 * EPT * kWave * sizeof(float);
+      if (grad) hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, true>), grid, block, lds1, stream, G);
+      else hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, false>), grid, block, lds1, stream, G);
+    }
     return (int)hipGetLastError();
   }
   const bool uniform = G.wu == nullptr && G.wv == nullptr;   // no weights: CDFs in closed form, no searches

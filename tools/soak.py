@@ -122,6 +122,22 @@ def main(budget=None):
             _, c_c, _ = shw.ssw_pair_losses(x, y2.detach(), U, 1, return_slices=True, u_weights=wu, v_weights=wv)
             if not torch.allclose(c_a, c_b, rtol=2e-3, atol=2e-7):
                 problems.append(f"weighted symmetry: max rel {float(((c_a - c_b).abs() / (c_a + 1e-6)).max())}")
+            if kind != "grid":
+                # weighted p = 1 (walking level-median kernel): explicit uniform weights must give the unweighted
+                # level-median kernel's values (two implementations); the tolerance rule of the p = 1 merge-vs-search
+                # check above (the median threshold makes single slices jump).  (No symmetry check: the reference's
+                # formula is not symmetric -- smallest level reaching 0.5, [0, first atom) left out.)
+                w1 = torch.full((n,), 1.0 / n, device=dev)
+                w2 = torch.full((m2,), 1.0 / m2, device=dev)
+                poison()
+                _, c_1u, _ = shw.ssw_pair_losses(x, y2.detach(), U, 1, return_slices=True)
+                poison()
+                _, c_1w, _ = shw.ssw_pair_losses(x, y2.detach(), U, 1, return_slices=True, u_weights=w1, v_weights=w2)
+                for name, a_, b_ in (("p=1 uniform weights vs none", c_1w, c_1u),):
+                    diff = (a_ - b_).abs()
+                    off = diff > 1e-4 * b_ + 5e-7
+                    if float(off.float().mean()) > 0.004 or bool((diff > 3.0 / min(n, m2) + 1e-5).any()):
+                        problems.append(f"{name}: {int(off.sum())} slices differ, max abs {float(diff.max())}")
             # unequal sizes WITHOUT weights take the closed-form-CDF kernel; the same problem with explicit uniform
             # weights takes the searched-CDF kernel: two implementations of one function; and W(mu,nu) == W(nu,mu)
             if m2 != n:
