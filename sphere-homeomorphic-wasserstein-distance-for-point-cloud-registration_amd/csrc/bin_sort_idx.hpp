@@ -41,7 +41,7 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
   static_assert(BPL >= 4 && BPL % 4 == 0, "bin sort needs >= 4 bins per lane");
   float key[EPT];
   unsigned pk[EPT];
-  float part = load_coords<EPT, FULL, CHAINED>(X, count, lane, U, key);
+  float part = load_coords<EPT, FULL, CHAINED, kWave, true>(X, count, lane, U, key);
   asm volatile("" : "+v"(part));                           // see sorted_with_indices
 #pragma unroll
   for (int r = 0; r < EPT; ++r) pk[r] = PK::pack(key[r], r * kWave + lane, FULL || r * kWave + lane < count);

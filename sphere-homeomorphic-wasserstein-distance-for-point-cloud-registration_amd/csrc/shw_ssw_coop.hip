@@ -16,8 +16,10 @@ namespace shw {
 #define SHW_COOP_MINW 0      // 0: let the register allocator choose
 #endif
 
+// (any n keeps the sorted target in registers for re-centring the extended rows: without the bound the allocator
+//  takes 259 registers and halves the occupancy -- 0.43 instead of 0.25 ms at n = 3000, B = 43, L = 256)
 template <int EPT, int W, int PMODE, bool FULL>
-__global__ __launch_bounds__(W * 64) void ssw_forward_coop_kernel(SswArgs A) {
+__global__ __launch_bounds__(W * 64, FULL ? 1 : 2) void ssw_forward_coop_kernel(SswArgs A) {
   typedef Coop<EPT, W> C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* cnt = reinterpret_cast<unsigned*>(lds);
@@ -52,8 +54,12 @@ __global__ __launch_bounds__(W * 64) void ssw_forward_coop_kernel(SswArgs A) {
     } else {
       part_v = wave_sum_uniform(part, lane);
       if constexpr (W > 1) __syncthreads();                     // every wave has read its keys back from buf
+      if constexpr (FULL) {
 #pragma unroll
-      for (int r = 0; r < EPT; ++r) buf[r * C::NCOL + gl] = key[r];
+        for (int r = 0; r < EPT; ++r) buf[r * C::NCOL + gl] = key[r];
+      }
+      // (any n: the sorted target stays in `key` and is written as pre-rotated extended rows once the first guess
+      //  of the shift is known -- ssw_common.hpp, ExtRows)
     }
   }
   float* sums = redf + 8 * W;
@@ -71,12 +77,25 @@ __global__ __launch_bounds__(W * 64) void ssw_forward_coop_kernel(SswArgs A) {
   bool lo_tight = false, hi_tight = false;
   int step = 1;
   float cm = 0.f, c0 = 0.f, cp = 0.f;
+  typedef ExtRows<EPT, C::NCOL> X;
+  static_assert(X::FLOATS <= C::NB + C::CAP, "extended rows take the counters' and the buffer's place");
+  float* ext = lds;
+  int kc = k;
+  if constexpr (!FULL) ext_rows_write<EPT, C::NCOL>(key, ext, gl, n, kc);   // (the barrier above: cnt / buf are free)
   for (int it = 0; it < 64; ++it) {
     int g2 = gl;
     asm volatile("" : "+v"(g2));
     float pm, p0, pp;
-    if constexpr (FULL) shift_costs3_full<EPT, PMODE, C::NCOL>(u, buf, g2, k, A.p, A.p_int, pm, p0, pp);
-    else shift_costs3<EPT, PMODE, C::NCOL>(u, buf, g2, n, k, A.p, A.p_int, pm, p0, pp);
+    if constexpr (FULL) {
+      shift_costs3_full<EPT, PMODE, C::NCOL>(u, buf, g2, k, A.p, A.p_int, pm, p0, pp);
+    } else {
+      // (every wave passed the barrier of the previous evaluation's sum after its last read of the rows)
+      if (k - kc >= X::M || kc - k >= X::M) {                   // uniform over the workgroup: re-centre the rows
+        kc = k;
+        ext_rows_write<EPT, C::NCOL>(key, ext, g2, n, kc);
+      }
+      shift_costs3_ext<EPT, PMODE, EPT, C::NCOL>(u, ext, g2, n, k - kc, A.p, A.p_int, pm, p0, pp);
+    }
     if constexpr (W > 1) {
       float* slot = redf + (it & 1) * 4 * W;                    // two parities: one barrier per evaluation
       if (lane == 0) { slot[wave * 4] = pm; slot[wave * 4 + 1] = p0; slot[wave * 4 + 2] = pp; }

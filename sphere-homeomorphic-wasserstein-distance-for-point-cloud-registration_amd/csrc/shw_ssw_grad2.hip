@@ -24,10 +24,13 @@ namespace shw {
 #ifndef SHW_GRAD2_MINW
 #define SHW_GRAD2_MINW 3
 #endif
-constexpr int grad2_waves_per_simd(int ept) { return ept == 32 ? SHW_GRAD2_MINW : 4; }
+#ifndef SHW_GRAD2_MINW_PARTIAL
+#define SHW_GRAD2_MINW_PARTIAL 3
+#endif
+constexpr int grad2_waves_per_simd(int ept, bool full) { return ept == 32 ? (full ? SHW_GRAD2_MINW : SHW_GRAD2_MINW_PARTIAL) : 4; }
 
 template <int EPT, int PMODE, bool FULL>
-__global__ __launch_bounds__(128, grad2_waves_per_simd(EPT)) void ssw_forward_grad2_kernel(SswArgs A) {
+__global__ __launch_bounds__(128, grad2_waves_per_simd(EPT, FULL)) void ssw_forward_grad2_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave;
   constexpr int HALF = EPT / 2;

@@ -297,18 +297,20 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
 // offset -- 1 VALU per fetch.  The search seldom leaves |d| < M (the first guess is exact for evenly spaced
 // targets and galloping starts with steps 1, 2, 4, ...); when it does the rows are rewritten around the new k.
 // ---------------------------------------------------------------------------------------------
-template <int EPT>
+// NCOL > 64 (cooperative kernel): NCOL lanes of NCOL/64 waves hold the slice, `lane` is the lane number within the
+// slice and the writers synchronise with workgroup barriers.
+template <int EPT, int NCOL = 64>
 struct ExtRows {
   static constexpr int M = EPT;                 // half width of the halo = reach of the shift without a rewrite
-  static constexpr int RS = 66;                 // columns per row: (64*EPT + 2M) / EPT
+  static constexpr int RS = NCOL + 2;           // columns per row: (NCOL*EPT + 2M) / EPT
   static constexpr int FLOATS = EPT * RS;
-  static constexpr int TRASH = ((EPT - 1) * RS + 65) * 4;      // byte offset of the last slot: never a valid E for n < 64*EPT
+  static constexpr int TRASH = ((EPT - 1) * RS + NCOL + 1) * 4;   // byte offset of the last slot: never a valid E for n < NCOL*EPT
 };
 
 // v[r] = sorted target at position lane*EPT + r (anything at positions >= n).  n > M required (size classes give n > 32*EPT).
-template <int EPT>
+template <int EPT, int NCOL = 64>
 __device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext, int lane, int n, int kc) {
-  typedef ExtRows<EPT> X;
+  typedef ExtRows<EPT, NCOL> X;
   constexpr int LOG = __builtin_ctz(EPT);
   // c1 = (M - kc) mod n and the turn s it absorbs: ext[p + c1] = v[p] - s, or, past the end, ext[p + c1 - n] = v[p] - s - 1
   const int t = X::M - kc;                                       // in [M - n, M + n]
@@ -332,7 +334,7 @@ __device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext
     off = pos < n ? off + lane4 : X::TRASH;
     *reinterpret_cast<float*>(bytes + off) = v[r] + (wrap ? vw : vn);
   }
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (NCOL > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   // halo: ext[n + l] = ext[l] + 1 for l < 2M (one entry per lane; 2M <= 64)
   {
     const int src = lane, dst = n + lane;
@@ -341,15 +343,15 @@ __device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext
     const float x = *reinterpret_cast<const float*>(bytes + so);
     *reinterpret_cast<float*>(bytes + (lane < 2 * X::M ? d_o : X::TRASH)) = x + 1.f;
   }
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (NCOL > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
 }
 
 // c(k-1), c(k), c(k+1) for k = kc + d, |d| < M, on registers [r_base, r_base + NR) of every lane (u holds those NR
 // source atoms; atoms at positions >= n are masked out).  Sums over the wave, valid in every lane.
-template <int EPT, int PMODE, int NR = EPT>
+template <int EPT, int PMODE, int NR = EPT, int NCOL = 64>
 __device__ __forceinline__ void shift_costs3_ext(const float (&u)[NR], const float* ext, int lane, int n, int d,
                                                  float p, int p_int, float& cm, float& c0, float& cp, int r_base = 0) {
-  typedef ExtRows<EPT> X;
+  typedef ExtRows<EPT, NCOL> X;
   constexpr int LOG = __builtin_ctz(EPT);
   const int base = d - 1 + X::M + r_base;                        // >= 0, wave-uniform
   const int bl = base & (EPT - 1), bh = base >> LOG;
@@ -436,25 +438,35 @@ __device__ __forceinline__ int solve_shift_ext(const float (&u)[EPT], const floa
 // front and the raw points take 96 registers (shw_ssw_p1_merge.hip).
 // NCOL: lanes that share the cloud (64 for one wave; 64*W when W waves of a workgroup own a slice together, `lane`
 // then being the index among those lanes): lane owns points r*NCOL + lane.
-template <int EPT, bool FULL = false, bool CHAINED = false, int NCOL = kWave>
+// FOLD: how the masked classes take coordinate-row mode, see below.
+template <int EPT, bool FULL = false, bool CHAINED = false, int NCOL = kWave, bool FOLD = false>
 __device__ __forceinline__ float load_coords(const float* __restrict__ X, int count, int lane,
                                              const float (&U)[6], float (&key)[EPT], int live_count = -1) {
   // `count` bounds the addresses (clamp), `live_count` (default: count) says how many of the 64*EPT slots are
   // real atoms; they differ only for the trailing chunks of the multi-wave kernel
   if (live_count < 0) live_count = count;
   float acc = 0.f;
-  if (U[0] != U[0]) {
-    // coordinate-row mode (shw_circle_ot): X holds circle coordinates, one float per atom
+  // coordinate-row mode (shw_circle_ot): X holds circle coordinates, one float per atom (U[0] is NaN then): a branch
+  // -- or, FOLD, part of the one code path (record stride 1 or 3 and a final select).  As a branch it left both forms'
+  // state live at the join in the two-wave training kernel's masked classes: 14 -> 39 spilled registers, N=2000
+  // training 0.62 -> 0.80 ms; folded it costs 2 + 1 VALU per point.  (The loss kernels spill less with the branch.)
+  const bool rows = U[0] != U[0];
+  constexpr bool kFold = FOLD && !FULL;
+  if constexpr (!kFold) {
+    if (rows) {
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int i = r * NCOL + lane;
-      const float c = X[FULL ? i : min(i, count - 1)];
-      const bool live = FULL || (i < live_count);
-      acc += live ? c : 0.f;
-      key[r] = live ? c : __builtin_inff();
+      for (int r = 0; r < EPT; ++r) {
+        const int i = r * NCOL + lane;
+        const float c = X[FULL ? i : min(i, count - 1)];
+        const bool live = FULL || (i < live_count);
+        acc += live ? c : 0.f;
+        key[r] = live ? c : __builtin_inff();
+      }
+      return acc;
     }
-    return acc;
   }
+  const int wide = (kFold && rows) ? 0 : -1;       // all ones: 12-byte records
+  const int o1 = (kFold && rows) ? 0 : 1, o2 = (kFold && rows) ? 0 : 2;
   constexpr int CH = EPT < 8 ? EPT : 8;            // 8 points (24 loads) in flight per lane
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
@@ -466,7 +478,8 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
     for (int j = 0; j < CH; ++j) {
       const int raw = (r0 + j) * NCOL + lane;
       const int i = FULL ? raw : min(raw, count - 1);           // clamp: branch-free, always in bounds
-      px[j] = X[3 * i]; py[j] = X[3 * i + 1]; pz[j] = X[3 * i + 2];
+      const int i3 = kFold ? i + ((i & wide) << 1) : 3 * i;     // 3 i, or i for rows of coordinates
+      px[j] = X[i3]; py[j] = X[i3 + (kFold ? o1 : 1)]; pz[j] = X[i3 + (kFold ? o2 : 2)];
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -475,7 +488,8 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
       // all-zero point projects to (+0, +0) -- never -0 -- and lands on coordinate 0 (G4 fixture)
       const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
       const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], fmaf(px[j], U[1], 0.f)));
-      const float c = circle_coord(a, b);
+      float c = circle_coord(a, b);
+      if constexpr (kFold) c = rows ? px[j] : c;
       const bool live = FULL || (i < live_count);
       acc += live ? c : 0.f;
       key[r0 + j] = live ? c : __builtin_inff();
