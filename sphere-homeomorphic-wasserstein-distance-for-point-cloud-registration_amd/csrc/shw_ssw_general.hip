@@ -548,7 +548,6 @@ template <int EPT, int PMODE, int C>
 __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false>& T, float theta, int lane, float p,
                                 int p_int, float& d_plus, float& d_minus, int (&anchor)[C], bool warm,
                                 float& cost_scale) {
-  constexpr int P = EPT * kWave;
   constexpr int LEN = EPT / C;
   static_assert(EPT % C == 0, "chains of equal length");
   Rotated<EPT, false> R;

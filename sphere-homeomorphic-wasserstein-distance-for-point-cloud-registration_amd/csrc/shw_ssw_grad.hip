@@ -257,6 +257,7 @@ int dispatch_forward_grad(SswArgs& A, hipStream_t stream) {
   {
     const int ept = ept_for(A.n, A.m);
     if (ept >= 8 && ept <= 32 && !grad_one_wave_forced()) return dispatch_forward_grad2(A, stream);   // shw_ssw_grad2.hip
+    if ((ept == 64 || ept == 128) && !grad_one_wave_forced()) return dispatch_forward_grad_coop(A, stream);   // shw_ssw_grad_coop.hip
   }
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT

@@ -670,6 +670,7 @@ inline int ept_for(int n, int m) {
 int dispatch_forward(SswArgs& A, hipStream_t stream);        // shw_ssw_fwd.hip   p != 1, loss only
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream);   // shw_ssw_grad.hip  p != 1, loss + coefficients
 int dispatch_forward_grad2(SswArgs& A, hipStream_t stream);  // shw_ssw_grad2.hip two waves per slice, 257..2048 points
+int dispatch_forward_grad_coop(SswArgs& A, hipStream_t stream);   // shw_ssw_grad_coop.hip 2 / 4 waves per slice, 2049..8192 points
 int dispatch_level_median(SswArgs& A, hipStream_t stream);   // shw_ssw_p1.hip    p == 1 (coef_s != NULL: + coefficients)
 int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                      float* slice_theta, hipStream_t stream);   // shw_ssw_general.hip  p != 1, n != m / weights

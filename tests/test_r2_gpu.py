@@ -213,6 +213,54 @@ def test_p1_search_kernel_small_size_instantiations_agree_with_the_merge_kernel(
         grad_close(np.array(a["gx"]), np.array(b["gx"]), loose=0.1)
 
 
+# ------------------------------------------------------------------------- cooperative training kernel, n > 2048
+_GRADCOOP_SCRIPT = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import shw_amd
+out = {}
+for (n, kind) in ((3000, "sphere"), (4096, "sphere"), (8192, "sphere"), (5000, "lattice"), (4096, "lattice")):
+    g = torch.Generator().manual_seed(77 * n + len(kind))
+    x, y = torch.randn(2, n, 3, generator=g), torch.randn(2, n, 3, generator=g)
+    if kind == "sphere":
+        x, y = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(y, dim=-1)
+    else:                                # few lattice sites: masses of duplicate points, i.e. exact coordinate ties
+        x, y = torch.round(x * 4) / 4 + 0.01, torch.round(y * 4) / 4 + 0.01
+    U = torch.linalg.qr(torch.randn(2, 5, 3, 2, generator=g))[0]
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, shift = shw_amd.ssw_pair_losses(xs, ys, U.cuda(), p=2, return_slices=True)
+    (pair * torch.tensor([1.0, -0.5], device="cuda")).sum().backward()
+    out[f"{n}{kind}"] = {"cost": cost.cpu().tolist(), "shift": shift.cpu().tolist(),
+                         "gx": xs.grad.cpu().numpy().tolist(), "gy": ys.grad.cpu().numpy().tolist()}
+print(json.dumps(out))
+"""
+
+
+def test_cooperative_training_kernel_agrees_with_the_one_wave_kernels_above_2048_points(shw):
+    """Round 2: 2049..8192 points train through shw_ssw_grad_coop.hip (2 / 4 waves per slice, cooperative distribution
+    sort on 64-bit items).  The one-wave kernels it replaces (packed words at 4096, 64-bit items on the bitonic network
+    at 8192) stay reachable with SHW_GRAD_KERNEL=onewave: the same seeded cases in two subprocesses must give the same
+    shifts and per-slice costs to 3e-6 and -- both sorts being stable -- the same gradients also on clouds made of
+    duplicate points (lattice: long runs of equal coordinates, which take the cooperative sort's bitonic fallback)."""
+    res = {}
+    for forced in ("", "onewave"):
+        env = dict(os.environ, SHW_GRAD_KERNEL=forced)
+        r = subprocess.run([sys.executable, "-c", _GRADCOOP_SCRIPT, ROOT], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[forced] = json.loads(r.stdout.strip().split("\n")[-1])
+    for key in res[""]:
+        a, b = res[""][key], res["onewave"][key]
+        ca, cb = np.array(a["cost"]), np.array(b["cost"])
+        assert np.all(np.abs(ca - cb) <= 3e-6 * np.abs(cb) + 1e-12), key
+        same_shift = np.array(a["shift"]) == np.array(b["shift"])
+        assert same_shift.mean() > 0.99, key                      # (exact cost ties may pick either shift)
+        for f in ("gx", "gy"):
+            ga, gb = np.array(a[f]), np.array(b[f])
+            assert np.isfinite(ga).all()
+            if same_shift.all():
+                assert np.abs(ga - gb).max() <= 1e-6 * np.abs(gb).max() + 1e-12, (key, f)
+
+
 # ------------------------------------------------------------------------------------------- config 2, full size
 def test_full_size_properties_config2_with_chamfer(shw):
     """BASELINE configs[1]: batch=64, N=1024, L=256, sliced-W loss vs Chamfer, fp32 -- at full size, through
