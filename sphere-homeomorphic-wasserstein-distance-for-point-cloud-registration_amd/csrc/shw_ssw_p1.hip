@@ -222,6 +222,7 @@ static int launch_level_median(SswArgs& A, hipStream_t stream) {
 
 int dispatch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream);
 int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream);   // shw_ssw_p1_coop.hip
+bool level_median_coop_trains(int n, int m);
 
 // SHW_P1_SEARCH_KERNEL=1 (diagnostic): use the one-wave search kernel at every size
 static bool p1_search_kernel_forced() {
@@ -236,8 +237,9 @@ int dispatch_level_median(SswArgs& A, hipStream_t stream) {
     const int mg = A.m / g, ng = A.n / g;
     return dispatch_level_median_merge(A, mg, ng, 1.f / ((float)A.n * (float)mg), stream);
   }
-  if (A.coef_s == nullptr && !p1_search_kernel_forced()) {
-    // loss only above 2048 points: 4 / 8 waves per slice, merge by one cooperative distribution sort (shw_ssw_p1_coop.hip)
+  if ((A.coef_s == nullptr || level_median_coop_trains(A.n, A.m)) && !p1_search_kernel_forced()) {
+    // above 2048 points: 4 / 8 waves per slice, merge by one cooperative distribution sort (shw_ssw_p1_coop.hip;
+    // training up to n + m = 8192)
     const int g = gcd_int(A.n, A.m);
     const int mg = A.m / g, ng = A.n / g;
     return dispatch_level_median_coop(A, mg, ng, 1.f / ((float)A.n * (float)mg), stream);

@@ -1,4 +1,4 @@
-// shw_ssw_p1_coop.hip -- p == 1, loss only, 2048 < max(n, m) <= 8192: the level-median closed form of emd1D_circle
+// shw_ssw_p1_coop.hip -- p == 1, 2048 < max(n, m) <= 8192 (loss; training up to n + m = 8192): the level-median closed form of emd1D_circle
 // (max_spherical_sliced_w.py:210-247; shw_ssw_p1.hip has the formula and the reference's quirks) with the MERGE of
 // the two clouds done by ONE cooperative distribution sort (the one-wave search kernel it
 // replaces runs 64 / 128 atoms per lane and 12-13 LDS probes per atom: 1.7 / 3.8 ms per launch at 4096 / 8192 points).
@@ -14,7 +14,7 @@
 //     gap to the merged successor     = next key - key  (last live atom: 1 - key; [0, first atom) is not integrated)
 //     weighted median                 = integer bisection, one masked sum per step, added across the waves in wave order
 // Clearing the tag bit moves a coordinate by at most one ulp (6e-8): far inside the 1e-5 parity tolerance.
-#include "coop_sort.hpp"
+#include "coop_sort_kv.hpp"
 #include "ssw_common.hpp"
 
 namespace shw {
@@ -34,13 +34,18 @@ __device__ __forceinline__ int p1c_wave_min_int(int v, int lane) {
   return v;
 }
 
-template <int EPT, int W>
+// GRAD (training, n + m <= 8192): the same on 64-bit items (tagged coordinate bits << 32 | index inside the atom's own
+// cloud; coop_sort_kv.hpp): the merged atom carries its original index, so
+//     d cost / d coordinate = (|level_before - med| - |level - med|) / lcm      (first merged atom: -|level - med| / lcm)
+// goes straight into the cloud's staging row (the item buffer's place) and is stored coalesced: every coefficient
+// written exactly once, no atomics (rows feed ssw_backward_points_kernel).
+template <int EPT, int W, bool GRAD>
 __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
   typedef Coop<EPT, W> C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* cnt = reinterpret_cast<unsigned*>(lds);
-  float* buf = lds + C::NB;
-  int* red = reinterpret_cast<int*>(lds + C::NB + C::CAP);     // coop_sort: [0, 2W); afterwards the exchanges below
+  float* buf = lds + C::NB;                                     // C::CAP floats, GRAD: 2 C::CAP (items)
+  int* red = reinterpret_cast<int*>(lds + C::NB + (GRAD ? 2 : 1) * C::CAP);   // coop_sort: [0, 2W); then the exchanges below
   float* redf = reinterpret_cast<float*>(red);
   static_assert(C::RED >= 9 * W, "cross-wave scratch");
   int* x_tags = red;                                            // [W] target atoms per wave
@@ -95,7 +100,20 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                                              // counters zeroed
-  coop_sort<EPT, W, false>(key, wave, lane, total_live, cnt, buf, red);
+  int idx[GRAD ? EPT : 1];
+  if constexpr (GRAD) {
+    item_t it[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * C::NCOL + gl;
+      it[r] = make_item(key[r], i < n ? i : i - n);
+    }
+    coop_sort_kv<EPT, W, false>(it, wave, lane, total_live, cnt, reinterpret_cast<item_t*>(buf), red);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) { key[r] = item_key(it[r]); idx[r] = item_idx(it[r]); }
+  } else {
+    coop_sort<EPT, W, false>(key, wave, lane, total_live, cnt, buf, red);
+  }
   // merged position of key[r]: g = gl*EPT + r; live iff g < n + m (pads are +inf)
 
   // ---- level numerators and gaps -------------------------------------------------------------------------------------
@@ -166,6 +184,31 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
   }
   const int med = lo;
 
+  // ---- gradient coefficients --------------------------------------------------------------------------------------------
+  if constexpr (GRAD) {
+    float* stage_s = buf;                                       // by original index; the item buffer is free (the sort's
+    float* stage_t = buf + C::CAP;                              // last barrier is behind every wave)
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int g = g0 + r;
+      const bool live = g < total_live;
+      const int t = as_i(key[r]) & 1;
+      const int pred = t ? num[r] + ng : num[r] - mg;           // level before the atom's own weight
+      const float before_abs = (g == 0) ? 0.f : (float)abs(pred - med);
+      const float coef = (before_abs - (float)abs(num[r] - med)) * inv_lcm;
+      if (live) (t ? stage_t : stage_s)[idx[r]] = coef;
+    }
+    __syncthreads();
+    float* cs = A.coef_s + (long)s * n;
+    float* ct = A.coef_t + (long)s * m;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int i = r * C::NCOL + gl;
+      if (i < n) cs[i] = stage_s[i];
+      if (i < m) ct[i] = stage_t[i];
+    }
+  }
+
   // ---- cost ------------------------------------------------------------------------------------------------------------
   float acc = 0.f;
 #pragma unroll
@@ -182,14 +225,14 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
   }
 }
 
-template <int EPT, int W>
+template <int EPT, int W, bool GRAD>
 static int launch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
   typedef Coop<EPT, W> C;
   const long total = (long)A.pairs * A.slices;
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
-  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  auto kern = ssw_level_median_coop_kernel<EPT, W>;
+  const size_t lds = (size_t)(C::LDS_FLOATS + (GRAD ? C::CAP : 0)) * sizeof(float);
+  auto kern = ssw_level_median_coop_kernel<EPT, W, GRAD>;
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds);
@@ -199,14 +242,20 @@ static int launch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, h
   return (int)hipGetLastError();
 }
 
-// p = 1, loss only, 2048 < max(n, m) <= 8192 (called from dispatch_level_median, shw_ssw_p1.hip)
+// training form available?  (n + m <= 8192: 12 bytes of LDS per merged slot; above that the item buffer alone is 128 KB)
+bool level_median_coop_trains(int n, int m) { return next_pow2(n + m) <= 8192; }
+
+// p = 1, 2048 < max(n, m) <= 8192 (called from dispatch_level_median, shw_ssw_p1.hip); coef_s != NULL: + coefficients
 int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
   const int padded = next_pow2(A.n + A.m);
+  const bool grad = A.coef_s != nullptr;
   switch (padded / 2048) {
 #ifndef SHW_DEV_ONLY_EPT
-    case 2: return launch_level_median_coop<32, 2>(A, mg, ng, inv_lcm, stream);
-    case 4: return launch_level_median_coop<32, 4>(A, mg, ng, inv_lcm, stream);
-    case 8: return launch_level_median_coop<32, 8>(A, mg, ng, inv_lcm, stream);
+    case 2: return grad ? launch_level_median_coop<32, 2, true>(A, mg, ng, inv_lcm, stream)
+                        : launch_level_median_coop<32, 2, false>(A, mg, ng, inv_lcm, stream);
+    case 4: return grad ? launch_level_median_coop<32, 4, true>(A, mg, ng, inv_lcm, stream)
+                        : launch_level_median_coop<32, 4, false>(A, mg, ng, inv_lcm, stream);
+    case 8: return grad ? (int)hipErrorInvalidValue : launch_level_median_coop<32, 8, false>(A, mg, ng, inv_lcm, stream);
 #endif
     default: return (int)hipErrorInvalidValue;
   }

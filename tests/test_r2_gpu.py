@@ -213,6 +213,55 @@ def test_p1_search_kernel_small_size_instantiations_agree_with_the_merge_kernel(
         grad_close(np.array(a["gx"]), np.array(b["gx"]), loose=0.1)
 
 
+# ------------------------------------------------------------------------- cooperative p = 1 kernels, n > 2048
+_P1_COOP_SCRIPT = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import shw_amd
+out = {}
+for (n, m, kind) in ((3000, 3000, "sphere"), (4096, 4096, "sphere"), (2500, 4000, "sphere"), (8192, 8192, "sphere"),
+                     (5000, 5000, "sphere"), (4096, 4096, "lattice"), (2049, 7, "sphere")):
+    g = torch.Generator().manual_seed(13 * n + m + len(kind))
+    x, y = torch.randn(n, 3, generator=g), torch.randn(m, 3, generator=g)
+    if kind == "sphere":
+        x, y = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(y, dim=-1)
+    else:                                # few lattice sites: duplicate points, exact coordinate ties within and across clouds
+        x, y = torch.round(x * 4) / 4 + 0.01, torch.round(y * 4) / 4 + 0.01
+    U = torch.linalg.qr(torch.randn(6, 3, 2, generator=g))[0]
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, _ = shw_amd.ssw_pair_losses(xs[None], ys[None], U.cuda(), p=1, return_slices=True)
+    pair.sum().backward()
+    _, cost_fwd, _ = shw_amd.ssw_pair_losses(x.cuda()[None], y.cuda()[None], U.cuda(), p=1, return_slices=True)
+    out[f"{n}x{m}{kind}"] = {"cost": cost[0].tolist(), "cost_fwd": cost_fwd[0].tolist(),
+                            "gx": xs.grad.cpu().numpy().tolist(), "gy": ys.grad.cpu().numpy().tolist()}
+print(json.dumps(out))
+"""
+
+
+def test_cooperative_p1_kernels_agree_with_the_search_kernel_above_2048_points(shw):
+    """Round 2: p = 1 above 2048 points runs shw_ssw_p1_coop.hip (the merge of the two clouds IS one cooperative
+    distribution sort of the tagged concatenation; training on 64-bit items up to n + m = 8192).  The one-wave search
+    kernel it replaces stays reachable with SHW_P1_SEARCH_KERNEL=1: same seeded cases in two subprocesses -- equal
+    sizes, unequal sizes, a lopsided pair, duplicate points -- costs to 2e-5 relative (the merge clears one mantissa
+    bit per coordinate), gradients up to near-tie swaps (the rule of the <= 2048 test above)."""
+    from helpers.compare import grad_close
+    res = {}
+    for forced in ("0", "1"):
+        env = dict(os.environ, SHW_P1_SEARCH_KERNEL=forced)
+        r = subprocess.run([sys.executable, "-c", _P1_COOP_SCRIPT, ROOT], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[forced] = json.loads(r.stdout.strip().split("\n")[-1])
+    for key in res["0"]:
+        a, b = res["0"][key], res["1"][key]
+        for field in ("cost", "cost_fwd"):
+            ca, cb = np.array(a[field]), np.array(b[field])
+            assert np.all(np.abs(ca - cb) <= 2e-5 * np.abs(cb) + 2e-7), (key, field)
+        if "lattice" not in key:         # (ties across the clouds: sub-gradients may differ between the two merges)
+            grad_close(np.array(a["gx"]), np.array(b["gx"]), loose=0.1)
+            grad_close(np.array(a["gy"]), np.array(b["gy"]), loose=0.1)
+        assert np.isfinite(np.array(a["gx"])).all() and np.isfinite(np.array(a["gy"])).all()
+
+
 # ------------------------------------------------------------------------- cooperative training kernel, n > 2048
 _GRADCOOP_SCRIPT = r"""
 import json, sys, numpy as np, torch
