@@ -26,11 +26,12 @@
 
 namespace shw {
 
-template <int EPT, int W>
+// KPB: keys per bin on average (the p = 1 training kernel at 16384 merged atoms takes 4 to fit the 160 KB of LDS)
+template <int EPT, int W, int KPB = SHW_COOP_KEYS_PER_BIN>
 struct Coop {
   static constexpr int NCOL = 64 * W;                       // lanes per slice
   static constexpr int CAP = EPT * NCOL;                    // keys per slice (padded)
-  static constexpr int NB = SHW_COOP_BINS_PER_KEY * CAP / SHW_COOP_KEYS_PER_BIN;    // bins
+  static constexpr int NB = SHW_COOP_BINS_PER_KEY * CAP / KPB;    // bins
   static constexpr int BPL = NB / NCOL;                     // bins per lane in the scan
   static constexpr int RED = 12 * W + 16;                   // ints / floats of cross-wave scratch
   static constexpr int LDS_FLOATS = NB + CAP + RED;
@@ -77,9 +78,9 @@ __device__ __forceinline__ void coop_bitonic(float (&key)[EPT], float* buf, int 
 }
 
 // Zero the counters (every wave its share).  The caller places a barrier between this and the next histogram.
-template <int EPT, int W>
+template <int EPT, int W, int KPB = SHW_COOP_KEYS_PER_BIN>
 __device__ __forceinline__ void coop_zero_counters(unsigned* cnt, int gl) {
-  typedef Coop<EPT, W> C;
+  typedef Coop<EPT, W, KPB> C;
 #pragma unroll
   for (int j = 0; j < C::BPL / 4; ++j)
     *reinterpret_cast<u32x4*>(cnt + j * (C::NCOL * 4) + gl * 4) = u32x4{0u, 0u, 0u, 0u};

@@ -63,10 +63,10 @@ __device__ __forceinline__ void binsort_boundary_kv(item_t (&x)[EPT], int lane) 
 // Sort the slice's items ascending.  On entry it[r] = make_item(coordinate, r*64W + gl) (pads: +inf, any index >= n);
 // on return it[r] is the item at sorted position gl*EPT + r.  cnt must be zero on entry and is left zeroed.
 // buf: 64 W EPT items.  Every wave of the workgroup must call this (it contains barriers).
-template <int EPT, int W, bool FULL>
+template <int EPT, int W, bool FULL, int KPB = SHW_COOP_KEYS_PER_BIN>
 __device__ __forceinline__ void coop_sort_kv(item_t (&it)[EPT], int wave, int lane, int n, unsigned* cnt, item_t* buf,
                                              int* red) {
-  typedef Coop<EPT, W> C;
+  typedef Coop<EPT, W, KPB> C;
   const int gl = wave * 64 + lane;
   char* bytes = reinterpret_cast<char*>(buf);
   // ---- 1. histogram ------------------------------------------------------------------------------------------
@@ -132,7 +132,7 @@ __device__ __forceinline__ void coop_sort_kv(item_t (&it)[EPT], int wave, int la
   __syncthreads();
   if (g > SHW_BINSORT_MAX_RUN) {
     // long runs (clustered data, duplicates): the network sorts it; counters re-zeroed for the next sort
-    coop_zero_counters<EPT, W>(cnt, gl);
+    coop_zero_counters<EPT, W, KPB>(cnt, gl);
     coop_bitonic_kv<EPT, W>(it, buf, wave, lane);
     return;
   }
@@ -149,7 +149,7 @@ __device__ __forceinline__ void coop_sort_kv(item_t (&it)[EPT], int wave, int la
     }
   }
   __syncthreads();
-  coop_zero_counters<EPT, W>(cnt, gl);                       // the offsets are dead: ready for the next sort
+  coop_zero_counters<EPT, W, KPB>(cnt, gl);                       // the offsets are dead: ready for the next sort
   // ---- 4. read back EPT consecutive positions ------------------------------------------------------------------
   auto read_back = [&]() {
 #pragma unroll

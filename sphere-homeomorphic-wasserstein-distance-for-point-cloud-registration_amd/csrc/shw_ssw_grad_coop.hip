@@ -22,17 +22,22 @@ namespace shw {
                                  // with 1 at 4096 points; W = 4: one workgroup per CU whatever the registers)
 #endif
 
+#ifndef SHW_GRADCOOP_KPB
+#define SHW_GRADCOOP_KPB 2       // keys per bin of the item sort
+#endif
+
 template <int EPT, int W, int PMODE, bool FULL>
 __global__ __launch_bounds__(W * 64, W == 2 ? SHW_GRADCOOP_MINW : 1) void ssw_forward_grad_coop_kernel(SswArgs A) {
-  typedef Coop<EPT, W> C;
+  constexpr int KPB = SHW_GRADCOOP_KPB;
+  typedef Coop<EPT, W, KPB> C;
   typedef ExtRows<EPT, C::NCOL> X;
   constexpr int LOG = __builtin_ctz(EPT);
-  static_assert(C::NB * 2 == C::CAP, "counters take half a row: the index row takes the other half");
+  static_assert(C::NB * 2 <= C::CAP, "counters take at most half a row: the index row takes the other half");
   static_assert(X::FLOATS <= 2 * C::CAP, "extended rows fit the item buffer");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* cnt = reinterpret_cast<unsigned*>(lds);                              // counters, then the target's index row
   unsigned short* idx_t = reinterpret_cast<unsigned short*>(lds);
-  unsigned short* idx_s = reinterpret_cast<unsigned short*>(lds + C::NB);        // the source's index row
+  unsigned short* idx_s = reinterpret_cast<unsigned short*>(lds + C::CAP / 2);   // the source's index row
   float* area = lds + C::CAP;                                                    // 2 CAP floats:
   item_t* buf = reinterpret_cast<item_t*>(area);                                 //   the sorts' item buffer,
   float* rows = area;                                                            //   then the target rows,
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(W * 64, W == 2 ? SHW_GRADCOOP_MINW : 1) void ssw_fo
   float U[6];
   load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
 
-  coop_zero_counters<EPT, W>(cnt, gl);
+  coop_zero_counters<EPT, W, KPB>(cnt, gl);
   item_t it[EPT];
   float u[EPT];
   float part_u = 0.f, part_v = 0.f;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(W * 64, W == 2 ? SHW_GRADCOOP_MINW : 1) void ssw_fo
       for (int r = 0; r < EPT; ++r) it[r] = make_item(key[r], r * C::NCOL + g2);
     }
     __syncthreads();                                            // counters zeroed; the previous sort's buffer read
-    coop_sort_kv<EPT, W, FULL>(it, wave, lane, n, cnt, buf, red);
+    coop_sort_kv<EPT, W, FULL, KPB>(it, wave, lane, n, cnt, buf, red);
     if (which == 0) {
       part_u = wave_sum_uniform(part, lane);
 #pragma unroll

@@ -1,4 +1,4 @@
-// shw_ssw_p1_coop.hip -- p == 1, 2048 < max(n, m) <= 8192 (loss; training up to n + m = 8192): the level-median closed form of emd1D_circle
+// shw_ssw_p1_coop.hip -- p == 1, 2048 < max(n, m) <= 8192 (loss and training): the level-median closed form of emd1D_circle
 // (max_spherical_sliced_w.py:210-247; shw_ssw_p1.hip has the formula and the reference's quirks) with the MERGE of
 // the two clouds done by ONE cooperative distribution sort (the one-wave search kernel it
 // replaces runs 64 / 128 atoms per lane and 12-13 LDS probes per atom: 1.7 / 3.8 ms per launch at 4096 / 8192 points).
@@ -34,14 +34,22 @@ __device__ __forceinline__ int p1c_wave_min_int(int v, int lane) {
   return v;
 }
 
-// GRAD (training, n + m <= 8192): the same on 64-bit items (tagged coordinate bits << 32 | index inside the atom's own
+// GRAD (training): the same on 64-bit items (tagged coordinate bits << 32 | index inside the atom's own
 // cloud; coop_sort_kv.hpp): the merged atom carries its original index, so
 //     d cost / d coordinate = (|level_before - med| - |level - med|) / lcm      (first merged atom: -|level - med| / lcm)
 // goes straight into the cloud's staging row (the item buffer's place) and is stored coalesced: every coefficient
 // written exactly once, no atomics (rows feed ssw_backward_points_kernel).
+// (training at W = 8: four keys per bin instead of two -- 16 KB of counters beside the 128 KB item buffer)
+#ifndef SHW_P1C_GRAD_KPB
+#define SHW_P1C_GRAD_KPB 4     // keys per bin of the training form (items: 4096 points 0.98 ms per step, with 2: 1.59)
+#endif
+template <int W, bool GRAD>
+constexpr int p1c_keys_per_bin() { return GRAD ? (W == 8 ? 4 : SHW_P1C_GRAD_KPB) : SHW_COOP_KEYS_PER_BIN; }
+
 template <int EPT, int W, bool GRAD>
 __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
-  typedef Coop<EPT, W> C;
+  constexpr int KPB = p1c_keys_per_bin<W, GRAD>();
+  typedef Coop<EPT, W, KPB> C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* cnt = reinterpret_cast<unsigned*>(lds);
   float* buf = lds + C::NB;                                     // C::CAP floats, GRAD: 2 C::CAP (items)
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
   const float* Xs = A.xs + (long)b * n * A.pstride;
   const float* Xt = A.xt + (long)b * m * A.pstride;
 
-  coop_zero_counters<EPT, W>(cnt, gl);
+  coop_zero_counters<EPT, W, KPB>(cnt, gl);
   // ---- project the concatenated clouds: lane owns atoms r*64W + gl ------------------------------------------------
   float key[EPT];
   constexpr int CH = 8;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
       const int i = r * C::NCOL + gl;
       it[r] = make_item(key[r], i < n ? i : i - n);
     }
-    coop_sort_kv<EPT, W, false>(it, wave, lane, total_live, cnt, reinterpret_cast<item_t*>(buf), red);
+    coop_sort_kv<EPT, W, false, KPB>(it, wave, lane, total_live, cnt, reinterpret_cast<item_t*>(buf), red);
 #pragma unroll
     for (int r = 0; r < EPT; ++r) { key[r] = item_key(it[r]); idx[r] = item_idx(it[r]); }
   } else {
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
 
 template <int EPT, int W, bool GRAD>
 static int launch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
-  typedef Coop<EPT, W> C;
+  typedef Coop<EPT, W, p1c_keys_per_bin<W, GRAD>()> C;
   const long total = (long)A.pairs * A.slices;
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
@@ -242,8 +250,8 @@ static int launch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, h
   return (int)hipGetLastError();
 }
 
-// training form available?  (n + m <= 8192: 12 bytes of LDS per merged slot; above that the item buffer alone is 128 KB)
-bool level_median_coop_trains(int n, int m) { return next_pow2(n + m) <= 8192; }
+// training form available?  (12 bytes of LDS per merged slot up to n + m = 8192, 9 above: four keys per bin)
+bool level_median_coop_trains(int n, int m) { return next_pow2(n + m) <= 16384; }
 
 // p = 1, 2048 < max(n, m) <= 8192 (called from dispatch_level_median, shw_ssw_p1.hip); coef_s != NULL: + coefficients
 int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
@@ -255,7 +263,8 @@ int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStr
                         : launch_level_median_coop<32, 2, false>(A, mg, ng, inv_lcm, stream);
     case 4: return grad ? launch_level_median_coop<32, 4, true>(A, mg, ng, inv_lcm, stream)
                         : launch_level_median_coop<32, 4, false>(A, mg, ng, inv_lcm, stream);
-    case 8: return grad ? (int)hipErrorInvalidValue : launch_level_median_coop<32, 8, false>(A, mg, ng, inv_lcm, stream);
+    case 8: return grad ? launch_level_median_coop<32, 8, true>(A, mg, ng, inv_lcm, stream)
+                        : launch_level_median_coop<32, 8, false>(A, mg, ng, inv_lcm, stream);
 #endif
     default: return (int)hipErrorInvalidValue;
   }
