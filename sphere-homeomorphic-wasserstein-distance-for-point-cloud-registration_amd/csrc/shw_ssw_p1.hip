@@ -230,19 +230,29 @@ static bool p1_search_kernel_forced() {
   return forced;
 }
 
+// SHW_P1_KERNEL=coop | merge (diagnostic / A-B): the cooperative kernel of shw_ssw_p1_coop.hip, or the two-wave merge
+// kernel, wherever they can run
+static int p1_kernel_forced() {
+  static const int forced = [] { const char* e = getenv("SHW_P1_KERNEL"); return e ? (e[0] == 'c' ? 1 : (e[0] == 'm' ? 2 : 0)) : 0; }();
+  return forced;
+}
+
 int dispatch_level_median(SswArgs& A, hipStream_t stream) {
-  if (A.n <= 2048 && A.m <= 2048 && !p1_search_kernel_forced()) {
-    // two waves per slice, merge by the sorting network (shw_ssw_p1_merge.hip)
+  const bool small = A.n <= 2048 && A.m <= 2048;
+  const bool grad = A.coef_s != nullptr;
+  // cooperative kernel (one distribution sort of the tagged concatenation, shw_ssw_p1_coop.hip): every shape above 2048
+  // points; at or below, the loss from 1025 merged atoms on (measured at n = m = 2048 / 1024: 0.42 / 0.20 ms against the
+  // merge kernel's 0.54 / 0.25) -- training stays with the merge kernel there (0.97 / 0.42 against 0.94 / 0.45 ms)
+  bool coop = small ? (!grad && A.n + A.m > 1024) : (!grad || level_median_coop_trains(A.n, A.m));
+  if (p1_kernel_forced() == 1 && A.n + A.m > 1024) coop = true;
+  if (p1_kernel_forced() == 2 && small) coop = false;
+  if (p1_search_kernel_forced()) coop = false;
+  if (coop || (small && !p1_search_kernel_forced())) {
     const int g = gcd_int(A.n, A.m);
     const int mg = A.m / g, ng = A.n / g;
-    return dispatch_level_median_merge(A, mg, ng, 1.f / ((float)A.n * (float)mg), stream);
-  }
-  if ((A.coef_s == nullptr || level_median_coop_trains(A.n, A.m)) && !p1_search_kernel_forced()) {
-    // above 2048 points: 4 / 8 waves per slice, merge by one cooperative distribution sort (shw_ssw_p1_coop.hip;
-    // training up to n + m = 8192)
-    const int g = gcd_int(A.n, A.m);
-    const int mg = A.m / g, ng = A.n / g;
-    return dispatch_level_median_coop(A, mg, ng, 1.f / ((float)A.n * (float)mg), stream);
+    const float inv_lcm = 1.f / ((float)A.n * (float)mg);
+    // (merge kernel: two waves per slice, merge by the sorting network, shw_ssw_p1_merge.hip)
+    return coop ? dispatch_level_median_coop(A, mg, ng, inv_lcm, stream) : dispatch_level_median_merge(A, mg, ng, inv_lcm, stream);
   }
   switch (ept_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT

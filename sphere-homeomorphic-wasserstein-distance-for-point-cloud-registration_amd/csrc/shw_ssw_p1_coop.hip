@@ -259,6 +259,8 @@ int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStr
   const bool grad = A.coef_s != nullptr;
   switch (padded / 2048) {
 #ifndef SHW_DEV_ONLY_EPT
+    case 1: return grad ? launch_level_median_coop<32, 1, true>(A, mg, ng, inv_lcm, stream)
+                        : launch_level_median_coop<32, 1, false>(A, mg, ng, inv_lcm, stream);
     case 2: return grad ? launch_level_median_coop<32, 2, true>(A, mg, ng, inv_lcm, stream)
                         : launch_level_median_coop<32, 2, false>(A, mg, ng, inv_lcm, stream);
     case 4: return grad ? launch_level_median_coop<32, 4, true>(A, mg, ng, inv_lcm, stream)

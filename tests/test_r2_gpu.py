@@ -211,6 +211,18 @@ def test_p1_search_kernel_small_size_instantiations_agree_with_the_merge_kernel(
             ca, cb = np.array(a[field]), np.array(b[field])
             assert np.all(np.abs(ca - cb) <= 2e-5 * np.abs(cb) + 2e-7), (key, field)
         grad_close(np.array(a["gx"]), np.array(b["gx"]), loose=0.1)
+    # the loss-only call takes the cooperative kernel from 1025 merged atoms on (end of round 2); the two-wave merge
+    # kernel it replaced there (SHW_P1_KERNEL=merge) and the cooperative kernel forced into training (=coop) must agree
+    for forced in ("merge", "coop"):
+        env = dict(os.environ, SHW_P1_SEARCH_KERNEL="0", SHW_P1_KERNEL=forced)
+        r = subprocess.run([sys.executable, "-c", _P1_SCRIPT, ROOT], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        other = json.loads(r.stdout.strip().split("\n")[-1])
+        for key in res["0"]:
+            for field in ("cost", "cost_fwd"):
+                ca, cb = np.array(res["0"][key][field]), np.array(other[key][field])
+                assert np.all(np.abs(ca - cb) <= 2e-5 * np.abs(cb) + 2e-7), (forced, key, field)
+            grad_close(np.array(res["0"][key]["gx"]), np.array(other[key]["gx"]), loose=0.1)
 
 
 # ------------------------------------------------------------------------- cooperative p = 1 kernels, n > 2048
