@@ -583,7 +583,8 @@ def test_g3_emd1d_circle_on_coordinate_rows(shw, golden, tag):
 
 @pytest.mark.parametrize("n,m,p,weighted", [(256, 256, 2, False), (100, 100, 3, False), (1000, 1000, 2, False),
                                             (3000, 3000, 2, False), (128, 100, 2, False), (64, 64, 2, True),
-                                            (200, 200, 1, False), (130, 77, 1, False)])
+                                            (200, 200, 1, False), (130, 77, 1, False), (700, 700, 1, False),
+                                            (3000, 2000, 1, False)])
 def test_circle_level_values_and_gradients_against_the_cpu_oracle(shw, n, m, p, weighted):
     """Coordinate rows through every kernel family (equal sizes, > 2048 atoms, unequal sizes, weights, p = 1):
     values and d cost / d coordinate against torch autograd of the CPU restatement."""
@@ -608,6 +609,10 @@ def test_circle_level_values_and_gradients_against_the_cpu_oracle(shw, n, m, p, 
         ref = ref_mirror.circular_ot_bisect(uc, vc, p=p, u_weights=wu, v_weights=wv)
     (ref * w).sum().backward()
     assert rel(cost.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
+    with torch.no_grad():                # the loss-only kernels read coordinate rows too (p = 1 from 1025 merged atoms on:
+        plain = shw.binary_search_circle(u.cuda(), v.cuda(), u_weights=None if wu is None else wu.cuda(),   # cooperative)
+                                         v_weights=None if wv is None else wv.cuda(), p=p)
+    assert rel(plain.cpu().numpy(), ref.detach().numpy()) < 2e-5
     loose = 0.2 if p == 1 else 2e-2
     # torch.rand coordinates sit on a 2^-24 grid: near-ties (and exact ties) are far more frequent than among projected
     # points, and every one moves two gradient entries by ~gap/n (measured: 28 of 9000 entries at 2.6e-4 of the
