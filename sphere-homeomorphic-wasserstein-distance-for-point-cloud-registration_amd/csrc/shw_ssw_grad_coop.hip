@@ -202,10 +202,12 @@ static int launch_forward_grad_coop(SswArgs& A, hipStream_t stream) {
 #define SHW_LAUNCH_GRAD_COOP(PM, FL)                                                                              \
   do {                                                                                                            \
     auto kern = ssw_forward_grad_coop_kernel<EPT, W, PM, FL>;                                                     \
-    if (lds > 64 * 1024) {                                                                                        \
+    static bool raised = false;       /* once per instantiation (and not inside a later stream capture) */          \
+    if (lds > 64 * 1024 && !raised) {                                                                             \
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
       if (e != hipSuccess) return (int)e;                                                                         \
+      raised = true;                                                                                              \
     }                                                                                                             \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, A);                                                        \
   } while (0)
