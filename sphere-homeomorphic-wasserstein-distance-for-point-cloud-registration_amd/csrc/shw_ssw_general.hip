@@ -213,6 +213,13 @@ constexpr int kWalkRounds = 6;
 // last column), so that the kWalkExt entries from ANY index are base + q * 256 bytes: one address, kWalkExt reads.
 constexpr int kWalkExt = 6;
 
+// weighted clouds with >= 8 atoms per lane evaluate their slopes by walking (cut_slopes_walk)
+template <int EPT, bool UNIFORM>
+constexpr bool general_walks() { return !UNIFORM && EPT >= 8; }
+template <int EPT, bool UNIFORM>
+constexpr int general_ext_floats() { return general_walks<EPT, UNIFORM>() ? kWalkExt * kWave : 0; }
+
+
 template <int EPT>
 __device__ __forceinline__ void fill_walk_ext(float* arr, int lane) {
 #pragma unroll
@@ -704,6 +711,17 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
       for (int a = 0; a < NA; ++a) R.atom(min(lane * EPT + r0 + a, m - 1), g[a], b[a]);
       if constexpr (UNIFORM) {
         lower_bounds2<EPT, UNIFORM, NA>(S, g, lt, le);
+      } else if constexpr (general_walks<EPT, UNIFORM>()) {  // window reads (the rows under the source CDF exist)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          const float k1[1] = {g[a]};
+          int p1[1] = {g[a] < walk_prev ? 0 : walk_ptr}, l1[1];    // (the wrap: levels restart at ~0)
+          walk_prev = g[a];
+          walk_window<EPT, 1>(S.cdf, n, k1, p1, l1);
+          walk_ptr = p1[0];
+          lt[a] = p1[0];
+          le[a] = l1[0];
+        }
       } else {
         bool alive[NA];
 #pragma unroll
@@ -859,12 +877,6 @@ __device__ __forceinline__ void prepare_from_indices(const GeneralArgs& G, int s
     __builtin_amdgcn_wave_barrier();
   }
 }
-
-// weighted clouds with >= 8 atoms per lane evaluate their slopes by walking (cut_slopes_walk)
-template <int EPT, bool UNIFORM>
-constexpr bool general_walks() { return !UNIFORM && EPT >= 8; }
-template <int EPT, bool UNIFORM>
-constexpr int general_ext_floats() { return general_walks<EPT, UNIFORM>() ? kWalkExt * kWave : 0; }
 
 template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
 __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
