@@ -202,12 +202,14 @@ static int launch_forward_grad_coop(SswArgs& A, hipStream_t stream) {
 #define SHW_LAUNCH_GRAD_COOP(PM, FL)                                                                              \
   do {                                                                                                            \
     auto kern = ssw_forward_grad_coop_kernel<EPT, W, PM, FL>;                                                     \
-    static bool raised = false;       /* once per instantiation (and not inside a later stream capture) */          \
-    if (lds > 64 * 1024 && !raised) {                                                                             \
+    static bool raised[64] = {};      /* once per instantiation and device (not inside a later stream capture) */   \
+    int dev_ = 0;                                                                                                 \
+    (void)hipGetDevice(&dev_);                                                                                    \
+    if (lds > 64 * 1024 && !raised[dev_ & 63]) {                                                                  \
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
       if (e != hipSuccess) return (int)e;                                                                         \
-      raised = true;                                                                                              \
+      raised[dev_ & 63] = true;                                                                                   \
     }                                                                                                             \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, A);                                                        \
   } while (0)

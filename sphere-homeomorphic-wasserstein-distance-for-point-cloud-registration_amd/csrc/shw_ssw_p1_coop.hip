@@ -241,12 +241,14 @@ static int launch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, h
   A.num_groups = (int)total;
   const size_t lds = (size_t)(C::LDS_FLOATS + (GRAD ? C::CAP : 0)) * sizeof(float);
   auto kern = ssw_level_median_coop_kernel<EPT, W, GRAD>;
-  static bool raised = false;           // once per instantiation (and not inside a later stream capture)
-  if (lds > 64 * 1024 && !raised) {
+  static bool raised[64] = {};          // once per instantiation and device (not inside a later stream capture)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 && !raised[dev & 63]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds);
     if (e != hipSuccess) return (int)e;
-    raised = true;
+    raised[dev & 63] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(W * 64), lds, stream, A, mg, ng, inv_lcm);
   return (int)hipGetLastError();

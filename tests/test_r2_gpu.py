@@ -670,3 +670,24 @@ def test_sinkhorn_gradients_against_autograd_of_the_restatement(shw, n, m):
     with torch.no_grad():                                   # no_grad: the value-only path, identical value
         plain, _, _ = shw.sinkhorn_pair_costs(xd, yd, 0.05, 25)
     assert torch.allclose(plain, cost.detach(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------- weighted clouds above 2048 points
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(3000, 2500), (4096, 4096)])
+@pytest.mark.parametrize("p", [2, 1])
+def test_weighted_clouds_above_2048_points_against_the_cpu_oracle(shw, n, m, p):
+    """The weighted kernels of round 2 (walking ranks with window rows, level-median in registers) in their 64-atoms-per-
+    lane class (66 / 102 KB of LDS per slice): per-slice costs against the float64 restatement, finite gradients."""
+    from oracle import ref_mirror
+    g = torch.Generator().manual_seed(3 + n + p)
+    x, y, U = unit_cloud(g, n), unit_cloud(g, m), directions(g, 3)
+    wu, wv = torch.rand(n, generator=g) + 0.1, torch.rand(m, generator=g) + 0.1
+    wu, wv = wu / wu.sum(), wv / wv.sum()
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, _ = shw.ssw_pair_losses(xs[None], ys[None], U.cuda(), p=p, return_slices=True, u_weights=wu.cuda(),
+                                        v_weights=wv.cuda())
+    pair.sum().backward()
+    ref = ref_mirror.per_slice_costs(x.double(), y.double(), U.double(), p=p, u_weights=wu.double(), v_weights=wv.double())
+    assert np.allclose(cost[0].detach().cpu().numpy(), ref.numpy(), rtol=5e-5, atol=1e-9)
+    assert torch.isfinite(xs.grad).all() and torch.isfinite(ys.grad).all()
