@@ -29,7 +29,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its only dynamic symbols */
 #define SHW_API __attribute__((visibility("default")))
 
-#define SHW_ABI_VERSION 2 /* 2: shw_ssw_backward_points takes per-pair upstream weights */
+#define SHW_ABI_VERSION 3 /* 2: shw_ssw_backward_points takes per-pair upstream weights; 3: shw_circle_ot takes `method` */
 #define SHW_MAX_POINTS 8192 /* per cloud, per pair */
 
 /* ABI version of the loaded library (== SHW_ABI_VERSION of the header it was built from). */
@@ -127,9 +127,14 @@ SHW_API int shw_ssw_forward_general(const float* xs, const float* xt, const floa
 /* ---------------------------------------------------------------------------------------------
  * Circle level: optimal transport between rows of circle COORDINATES (numbers in [0, 1]), no projection.
  * Replaces: binary_search_circle(u_values, v_values, u_weights, v_weights, p) (max_spherical_sliced_w.py:117-207)
- * for p != 1 and emd1D_circle(u_values, v_values, u_weights, v_weights) (:210-247) for p == 1, called on
- * (rows, n) / (rows, m) coordinate tensors -- the same kernels as the sliced entry points, their loaders reading
- * one float per atom instead of projecting a point on a frame.
+ * and emd1D_circle(u_values, v_values, u_weights, v_weights) (:210-247), called on (rows, n) / (rows, m) coordinate
+ * tensors -- the same kernels as the sliced entry points, their loaders reading one float per atom instead of
+ * projecting a point on a frame.
+ *   method : SHW_CIRCLE_BISECTION    = binary_search_circle for every p >= 1.  p == 1 is that function's DEFAULT (:117): the
+ *                                      bisection over the cut ending in Cost's p == 1 branch (:107-108), i.e. the true circular
+ *                                      W_1 -- NOT the value of emd1D_circle, whose formula leaves out the wrap segment;
+ *            SHW_CIRCLE_LEVEL_MEDIAN = emd1D_circle (p must be 1);
+ *            SHW_CIRCLE_AS_SLICED    = sliced_cost's own dispatch (:281-284): level-median for p == 1, bisection otherwise.
  *   u (rows, n), v (rows, m); wu / wv weights (n) / (m) shared (stride 0) or per row (stride n / m), NULL = uniform;
  *   cost (rows) out : W_p^p of every row;
  *   aux  (rows) out, may be NULL : int32 optimal shift k* (equal sizes, p != 1) or median level (p == 1), or the
@@ -137,8 +142,11 @@ SHW_API int shw_ssw_forward_general(const float* xs, const float* xt, const floa
  *   grad_u (rows*n), grad_v (rows*m) out, both NULL for a value-only call : d cost[row] / d u[row, i], / d v[row, j].
  * Same size limits as the sliced entry points (8192; 4096 with weights or n != m and p != 1).
  */
+#define SHW_CIRCLE_AS_SLICED 0
+#define SHW_CIRCLE_BISECTION 1
+#define SHW_CIRCLE_LEVEL_MEDIAN 2
 SHW_API int shw_circle_ot(const float* u, const float* v, const float* wu, const float* wv, long wu_row_stride,
-                          long wv_row_stride, int rows, int n, int m, float p, float* cost, float* aux,
+                          long wv_row_stride, int rows, int n, int m, float p, int method, float* cost, float* aux,
                           float* grad_u, float* grad_v, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

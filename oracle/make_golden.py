@@ -9,7 +9,8 @@ fixtures (data only: inputs and expected outputs) do.
 Run:  MPLBACKEND=Agg python oracle/make_golden.py            (every fixture)
       MPLBACKEND=Agg python oracle/make_golden.py g8 g9      (only the named ones)
 Fixture ids follow SURVEY.md 8c (G1..G5); G6/G7 were added in round 1, G8 (the phi-max wrappers) and G9 (the
-notebook's Euclidean sliced-W cell, exec'd from the .ipynb JSON) in round 2.
+notebook's Euclidean sliced-W cell, exec'd from the .ipynb JSON) in round 2, G3b (binary_search_circle at its default
+p = 1) and G10 (the notebooks' call shape: N = 1200, L = 100, cube-surface clouds, five Adam steps) in round 3.
 """
 from __future__ import annotations
 
@@ -205,6 +206,96 @@ def g9_notebook_euclidean_sw():
     np.savez_compressed(os.path.join(OUT, "g9_notebook_esw.npz"), **out)
 
 
+def g3b_bisection_at_p1(ref):
+    """G3b (round 3): `binary_search_circle` with its DEFAULT p = 1 (:117) -- the bisection ending in Cost's p == 1 branch
+    (:107-108), which is NOT emd1D_circle's value (that formula omits the wrap segment).  Same rows as
+    G3 plus weighted / unequal-size rows; values in f32 and f64 and the reference's autograd gradients (f32)."""
+    base = np.load(os.path.join(OUT, "g3_circle.npz"))
+    out = {}
+    for tag in ("64x64", "100x100", "256x256", "128x100"):
+        u = torch.from_numpy(base[f"u_{tag}"])
+        v = torch.from_numpy(base[f"v_{tag}"])
+        a, b = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        val = ref.binary_search_circle(a, b)                  # default p = 1
+        val.sum().backward()
+        out[f"bsc_p1_{tag}_f32"] = _np(val)
+        out[f"bsc_p1_{tag}_gu"] = _np(a.grad)
+        out[f"bsc_p1_{tag}_gv"] = _np(b.grad)
+        out[f"bsc_p1_{tag}_f64"] = _np(ref.binary_search_circle(u.double(), v.double(), p=1))
+    g = torch.Generator().manual_seed(20250110)
+    for (n, m) in ((96, 96), (80, 96), (1200, 1200), (1000, 750)):
+        u = torch.rand(6, n, generator=g)
+        v = torch.rand(6, m, generator=g)
+        wu = torch.rand(n, generator=g) + 0.1
+        wv = torch.rand(m, generator=g) + 0.1
+        wu, wv = wu / wu.sum(), wv / wv.sum()
+        tag = f"{n}x{m}"
+        out.update({f"u_{tag}": _np(u), f"v_{tag}": _np(v), f"wu_{tag}": _np(wu), f"wv_{tag}": _np(wv)})
+        a, b = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        val = ref.binary_search_circle(a, b, wu, wv, p=1)
+        val.sum().backward()
+        out[f"bsc_p1_w_{tag}_f32"] = _np(val)
+        out[f"bsc_p1_w_{tag}_gu"] = _np(a.grad)
+        out[f"bsc_p1_w_{tag}_gv"] = _np(b.grad)
+        out[f"bsc_p1_w_{tag}_f64"] = _np(ref.binary_search_circle(u.double(), v.double(), wu.double(), wv.double(), p=1))
+        out[f"bsc_p1_{tag}_f32"] = _np(ref.binary_search_circle(u, v, p=1))       # the same rows without weights
+        out[f"bsc_p1_{tag}_f64"] = _np(ref.binary_search_circle(u.double(), v.double(), p=1))
+        out[f"emd1_w_{tag}_f32"] = _np(ref.emd1D_circle(u, v, wu, wv))
+    np.savez_compressed(os.path.join(OUT, "g3b_bisection_p1.npz"), **out)
+
+
+def cube_surface_points(rng, num_points, side, bias=None):
+    """The notebooks' recipe for their clouds (Flow_cube.ipynb:127-200, restated): num_points // 6 rounds over the six
+    faces of [0, side]^3, in-face coordinates uniform -- or Beta(bias, 1), the "biased" target -- and the face's own
+    coordinate exactly 0 or side.  Un-normalised: the sliced loss projects them as they are."""
+    pts = []
+    for _ in range(num_points // 6):
+        for face in range(6):
+            a, b = (rng.uniform(0, side, 2) if bias is None else rng.beta(bias, 1, 2) * side)
+            fixed = 0.0 if face % 2 == 0 else side
+            pts.append({0: [fixed, a, b], 1: [a, fixed, b], 2: [a, b, fixed]}[face // 2])
+    return np.asarray(pts, dtype=np.float32)
+
+
+def g10_notebook_flow_shape(ref):
+    """G10 (round 3): the ONLY live call site of the spherical loss -- Flow_cube.ipynb:1381,
+    `sliced_wasserstein_sphere(evolving, target, 100, device, p=2)` with N = 1200 (:200), L = 100 (:747), an un-normalised
+    cube-surface evolving cloud against the biased cube-surface target (:7 of the parameter cell), followed by
+    loss.backward() and an Adam step (:1382-1383).  Stored: the reference's value, per-slice costs and d loss / d evolving
+    on FIXED directions (sliced_cost, p in {1, 2}); the same against a unit-sphere target; and the loss trace of five
+    Adam steps of that flow (lr = 0.01 as at :749) with one stored direction set per step."""
+    rng = np.random.default_rng(20250111)
+    g = torch.Generator().manual_seed(20250111)
+    N, L, steps, lr = 1200, 100, 5, 0.01
+    source = torch.from_numpy(cube_surface_points(rng, N, 1.0))
+    target = torch.from_numpy(cube_surface_points(rng, N, 1.0, bias=15))
+    sphere = F.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    U = torch.linalg.qr(torch.randn(L, 3, 2, generator=g))[0]
+    U_steps = torch.linalg.qr(torch.randn(steps, L, 3, 2, generator=g))[0]
+    out = {"source": _np(source), "target": _np(target), "sphere": _np(sphere), "U": _np(U), "U_steps": _np(U_steps),
+           "lr": np.float64(lr)}
+    for tname, tgt in (("cube", target), ("sphere", sphere)):
+        for p in (1, 2):
+            loss, per, gx, gy = pair_with_grads(ref, source, tgt, U, p)
+            out[f"loss_{tname}_p{p}"] = loss
+            out[f"per_slice_{tname}_p{p}"] = per
+            out[f"g_evolving_{tname}_p{p}"] = gx
+            out[f"g_target_{tname}_p{p}"] = gy
+    for p in (1, 2):
+        evolving = source.clone().requires_grad_(True)
+        opt = torch.optim.Adam([evolving], lr=lr, betas=(0.9, 0.999))
+        trace = []
+        for i in range(steps):
+            opt.zero_grad()
+            loss = ref.sliced_cost(evolving, target, U_steps[i], p=p)
+            loss.backward(retain_graph=True)
+            opt.step()
+            trace.append(float(loss))
+        out[f"flow_trace_p{p}"] = np.asarray(trace, dtype=np.float64)
+        out[f"flow_evolved_p{p}"] = _np(evolving)
+    np.savez_compressed(os.path.join(OUT, "g10_notebook_flow.npz"), **out)
+
+
 def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     ref = _load("ref_ssw", os.path.join(REF, "max_spherical_sliced_w.py"))
@@ -217,6 +308,10 @@ def main(only=()):
             g9_notebook_euclidean_sw()
         if "g7b" in only:
             g7b_sinkhorn_gradients()
+        if "g3b" in only:
+            g3b_bisection_at_p1(ref)
+        if "g10" in only:
+            g10_notebook_flow_shape(ref)
         for f in sorted(os.listdir(OUT)):
             print(f, os.path.getsize(os.path.join(OUT, f)))
         return 0
@@ -379,6 +474,8 @@ def main(only=()):
     g8_phi_max_wrappers(ref, ref_fast)
     g9_notebook_euclidean_sw()
     g7b_sinkhorn_gradients()
+    g3b_bisection_at_p1(ref)
+    g10_notebook_flow_shape(ref)
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

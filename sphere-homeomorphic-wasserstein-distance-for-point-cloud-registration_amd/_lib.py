@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("SHW_LIB_PATH") or os.path.join(_HERE, "libshw_hip.so"
 CSRC = os.path.join(_HERE, "csrc")
 
 _c_f32p = ctypes.c_void_p
-ABI_VERSION = 2           # include/shw.h SHW_ABI_VERSION
+ABI_VERSION = 3           # include/shw.h SHW_ABI_VERSION
+CIRCLE_AS_SLICED, CIRCLE_BISECTION, CIRCLE_LEVEL_MEDIAN = 0, 1, 2      # include/shw.h SHW_CIRCLE_*
 _SIGNATURES = {
     # name: (restype, argtypes)
     "shw_abi_version": (ctypes.c_int, []),
@@ -36,8 +37,8 @@ _SIGNATURES = {
                                                ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                                                ctypes.c_void_p]),
     "shw_circle_ot": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
-                                     ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
-                                     ctypes.c_void_p]),
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p,
+                                     _c_f32p, ctypes.c_void_p]),
     "shw_esw_forward": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long,
                                        ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_esw_backward_points": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,

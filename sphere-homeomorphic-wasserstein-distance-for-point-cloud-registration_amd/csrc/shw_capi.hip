@@ -208,13 +208,16 @@ int shw_ssw_forward_general(const float* xs, const float* xt, const float* dirs,
 }
 
 int shw_circle_ot(const float* u, const float* v, const float* wu, const float* wv, long wu_row_stride,
-                  long wv_row_stride, int rows, int n, int m, float p, float* cost, float* aux, float* grad_u,
+                  long wv_row_stride, int rows, int n, int m, float p, int method, float* cost, float* aux, float* grad_u,
                   float* grad_v, void* stream) {
   if (!u || !v || !cost) return (int)hipErrorInvalidValue;
+  if (method != SHW_CIRCLE_AS_SLICED && method != SHW_CIRCLE_BISECTION && method != SHW_CIRCLE_LEVEL_MEDIAN) return (int)hipErrorInvalidValue;
+  if (method == SHW_CIRCLE_LEVEL_MEDIAN && p != 1.f) return (int)hipErrorInvalidValue;   // emd1D_circle has no p != 1 branch
   if ((grad_u == nullptr) != (grad_v == nullptr)) return (int)hipErrorInvalidValue;
   if (rows < 0 || n < 1 || m < 1 || !(p >= 1.f)) return (int)hipErrorInvalidValue;
   if (rows == 0) return 0;
-  const bool general = wu || wv || (p != 1.f && n != m);
+  const bool bisect = p != 1.f || method == SHW_CIRCLE_BISECTION;
+  const bool general = wu || wv || (bisect && n != m);
   const int limit = general ? 4096 : SHW_MAX_POINTS;
   if (n > limit || m > limit) return (int)hipErrorInvalidValue;
   if ((wu_row_stride != 0 && wu_row_stride < n) || (wv_row_stride != 0 && wv_row_stride < m)) return (int)hipErrorInvalidValue;
@@ -224,9 +227,10 @@ int shw_circle_ot(const float* u, const float* v, const float* wu, const float* 
   A.coef_s = grad_u; A.coef_t = grad_v;
   A.pairs = rows; A.n = n; A.m = m; A.slices = 1; A.u_pair_stride = 0; A.pstride = 1;
   A.p = p; A.p_int = shw::small_integer_power(p);
+  A.bisect_p1 = (p == 1.f && bisect) ? 1 : 0;
   if (general) return shw::dispatch_general(A, wu, wv, wu_row_stride, wv_row_stride, aux, (hipStream_t)stream);
   A.slice_shift = reinterpret_cast<int32_t*>(aux);
-  if (p == 1.f) return shw::dispatch_level_median(A, (hipStream_t)stream);
+  if (!bisect) return shw::dispatch_level_median(A, (hipStream_t)stream);
   return grad_u ? shw::dispatch_forward_grad(A, (hipStream_t)stream) : shw::dispatch_forward(A, (hipStream_t)stream);
 }
 

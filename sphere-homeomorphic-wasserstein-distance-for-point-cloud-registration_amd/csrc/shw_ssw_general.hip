@@ -1431,7 +1431,7 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   A.num_groups = (int)total;
   const bool grad = A.coef_s != nullptr;
   const dim3 grid((unsigned)total), block(64);
-  if (A.p == 1.f) {
+  if (A.p == 1.f && !A.bisect_p1) {
     if constexpr (EPT >= 8) {
       const size_t lds1 = ((size_t)6 * EPT * kWave + 2 * kWalkExt * kWave) * sizeof(float);
       if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;

@@ -37,7 +37,9 @@ struct SswArgs {
                    // circle-level entry point shw_circle_ot; dirs is NULL then and a "pair" is one row)
   long u_pair_stride;
   float p;
-  int p_int;       // p if p is a small integer (2..8), else 0
+  int p_int;       // p if p is a small integer (1..8), else 0
+  int bisect_p1;   // p == 1 only: 1 = the reference's BISECTION at p = 1 (binary_search_circle's default p, :117, ending in
+                   // Cost's p == 1 branch :107-108) instead of the level-median formula of emd1D_circle; set by shw_circle_ot
   int num_groups;  // workgroups launched (for the XCD remap)
 };
 
@@ -661,7 +663,7 @@ __device__ __forceinline__ float sorted_with_indices(const float* __restrict__ X
 // ---------------------------------------------------------------------------------------------
 inline int small_integer_power(float p) {
   const int q = (int)p;
-  return ((float)q == p && q >= 2 && q <= 8) ? q : 0;
+  return ((float)q == p && q >= 1 && q <= 8) ? q : 0;
 }
 
 inline int next_pow2(int v) {

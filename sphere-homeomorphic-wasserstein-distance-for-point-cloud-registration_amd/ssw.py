@@ -293,7 +293,7 @@ class _CircleOT(torch.autograd.Function):
     kernels as d cost / d coordinate (what the sliced path calls its coefficient rows)."""
 
     @staticmethod
-    def forward(ctx, u, v, p, wu, wv, need_grad):
+    def forward(ctx, u, v, p, wu, wv, need_grad, method):
         lib = _lib.load()
         rows, n = u.shape
         m = v.shape[1]
@@ -311,7 +311,7 @@ class _CircleOT(torch.autograd.Function):
         wv_p, wv_s = wargs(wv, m)
         with torch.cuda.device(dev):
             _lib.check(lib.shw_circle_ot(uc.data_ptr(), vc.data_ptr(), wu_p, wv_p, wu_s, wv_s, rows, n, m, float(p),
-                                         cost.data_ptr(), None, gu.data_ptr() if need_grad else None,
+                                         int(method), cost.data_ptr(), None, gu.data_ptr() if need_grad else None,
                                          gv.data_ptr() if need_grad else None, _stream_ptr(dev)), "shw_circle_ot")
         if need_grad:
             ctx.save_for_backward(gu, gv)
@@ -321,7 +321,7 @@ class _CircleOT(torch.autograd.Function):
     def backward(ctx, g):
         gu, gv = ctx.saved_tensors
         w = g.to(torch.float32).unsqueeze(1)
-        return gu * w, gv * w, None, None, None, None
+        return gu * w, gv * w, None, None, None, None, None
 
 
 def _check_rows(name, t):
@@ -332,19 +332,31 @@ def _check_rows(name, t):
     return t.unsqueeze(0) if t.dim() == 1 else t
 
 
-def binary_search_circle(u_values, v_values, u_weights=None, v_weights=None, p=1):
-    """Reference `binary_search_circle` (max_spherical_sliced_w.py:117): circular OT cost W_p^p between rows of circle
-    coordinates in [0, 1], (rows, n) and (rows, m) -> (rows,).  p == 1 takes the level-median formula like the
-    reference's own dispatch in sliced_cost (:281-284).  Differentiable w.r.t. the coordinates."""
+def _circle_ot(u_values, v_values, u_weights, v_weights, p, method):
     u, v = _check_rows("u_values", u_values), _check_rows("v_values", v_values)
     if u.shape[0] != v.shape[0]:
         raise ValueError("u_values and v_values need the same number of rows")
+    if not (float(p) >= 1.0):
+        raise ValueError("p must be >= 1")
     wu = _check_weights("u_weights", u_weights, u.shape[1], u.shape[0], u.device)
     wv = _check_weights("v_weights", v_weights, v.shape[1], u.shape[0], u.device)
     need_grad = torch.is_grad_enabled() and (u.requires_grad or v.requires_grad)
-    return _CircleOT.apply(u, v, float(p), wu, wv, need_grad)
+    return _CircleOT.apply(u, v, float(p), wu, wv, need_grad, method)
+
+
+def binary_search_circle(u_values, v_values, u_weights=None, v_weights=None, p=1):
+    """Reference `binary_search_circle` (max_spherical_sliced_w.py:117-207): circular OT cost W_p^p between rows of circle
+    coordinates in [0, 1], (rows, n) and (rows, m) -> (rows,), by the bisection over the cut for EVERY p >= 1.  p = 1 is
+    the reference's default and ends in `Cost`'s p == 1 branch (:107-108): the true circular W_1, up to 2.5 % away from
+    what `emd1D_circle` returns (that formula leaves out the wrap segment; `sliced_cost` sends p == 1 there, :281-284).
+    Differentiable w.r.t. the coordinates (the cut is detached as at :207)."""
+    return _circle_ot(u_values, v_values, u_weights, v_weights, p, _lib.CIRCLE_BISECTION)
 
 
 def emd1D_circle(u_values, v_values, u_weights=None, v_weights=None, p=1):
-    """Reference `emd1D_circle` (:210): circular W_1 by the level-median formula (p = 1), otherwise the bisection."""
-    return binary_search_circle(u_values, v_values, u_weights, v_weights, p)
+    """Reference `emd1D_circle` (:210-247): the level-median formula for p = 1, quirk included.
+    The reference function has no branch for p != 1 (it falls off its end and returns None); that is an error here."""
+    if float(p) != 1.0:
+        raise ValueError("emd1D_circle is the p = 1 level-median formula (the reference returns None for p != 1); "
+                         "use binary_search_circle for p != 1")
+    return _circle_ot(u_values, v_values, u_weights, v_weights, 1.0, _lib.CIRCLE_LEVEL_MEDIAN)

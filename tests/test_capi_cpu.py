@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol(shw):
     lib = shw._lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.shw_abi_version() == 2
+    assert lib.shw_abi_version() == shw._lib.ABI_VERSION == 3
     assert lib.shw_max_points() == 8192
     assert lib.shw_ssw_coef_bytes(2, 10, 20, 3) == 2 * 3 * 30 * 4
 
@@ -65,3 +65,19 @@ def test_direction_sampling_on_cpu_matches_golden_stream(shw, golden):
     assert np.array_equal(shw.draw_directions(24, "cpu").numpy(), g["U_pair"])
     torch.manual_seed(int(g["seed"]))
     assert np.array_equal(shw.draw_directions(12, "cpu", batch=3).numpy(), g["U_batched"])
+
+
+def test_bench_gpus_2_starts_its_ranks_and_fails_only_at_device_selection():
+    """`python bench.py --gpus 2` on a box without GPUs must get through argument handling, start two
+    ranks under torch.distributed.run and fail where they select their device -- not exit with a usage error."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert res.returncode != 0
+    assert "starting 2 ranks" in res.stderr
+    assert "No HIP GPUs are available" in res.stderr
+    assert res.stdout.strip() == ""                      # no JSON line from a failed run

@@ -103,6 +103,78 @@ def test_g3_min_over_shifts_equals_bisection(golden, tag, tol, p):
     assert rel(cost, g[f"bsc_p{p}_{tag}_f64"]) < 1e-6
 
 
+# ---------------------------------------------------------------- G3b: binary_search_circle at its default p = 1 (round 3)
+G3B_PLAIN = ["64x64", "100x100", "256x256", "128x100", "96x96", "80x96", "1200x1200", "1000x750"]
+G3B_WEIGHTED = ["96x96", "80x96", "1200x1200", "1000x750"]
+
+
+def _g3b_rows(golden, tag):
+    g = golden("g3b_bisection_p1.npz")
+    src = g if f"u_{tag}" in g.files else golden("g3_circle.npz")
+    return g, T(src[f"u_{tag}"]), T(src[f"v_{tag}"])
+
+
+@pytest.mark.parametrize("tag", G3B_PLAIN)
+def test_g3b_bisection_at_p1_is_not_the_level_median(golden, tag):
+    """VERDICT r2 missing 1: `binary_search_circle(u, v)` (default p = 1, max_spherical_sliced_w.py:117) bisects and ends in
+    Cost's p == 1 branch (:107-108).  The restatement must return the reference's numbers -- and those differ from
+    emd1D_circle's (the omitted wrap segment) by far more than any tolerance in this suite."""
+    g, u, v = _g3b_rows(golden, tag)
+    assert rel(ref_mirror.circular_ot_bisect(u, v, p=1).numpy(), g[f"bsc_p1_{tag}_f32"]) < 2e-6
+    assert rel(ref_mirror.circular_ot_bisect(u.double(), v.double(), p=1).numpy(), g[f"bsc_p1_{tag}_f64"]) < 1e-12
+    level_median = ref_mirror.circular_w1_level_median(u, v).numpy()
+    assert rel(level_median, g[f"bsc_p1_{tag}_f32"]) > 1e-4
+
+
+@pytest.mark.parametrize("tag", G3B_WEIGHTED)
+def test_g3b_weighted_bisection_at_p1(golden, tag):
+    g, u, v = _g3b_rows(golden, tag)
+    wu, wv = T(g[f"wu_{tag}"]), T(g[f"wv_{tag}"])
+    a, b = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    got = ref_mirror.circular_ot_bisect(a, b, p=1, u_weights=wu, v_weights=wv)
+    got.sum().backward()
+    assert rel(got.detach().numpy(), g[f"bsc_p1_w_{tag}_f32"]) < 2e-6
+    assert np.abs(a.grad.numpy() - g[f"bsc_p1_w_{tag}_gu"]).max() < 1e-6
+    assert np.abs(b.grad.numpy() - g[f"bsc_p1_w_{tag}_gv"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["64x64", "100x100", "256x256", "96x96", "1200x1200"])
+def test_g3b_min_over_shifts_equals_the_bisection_at_p1(golden, tag):
+    """Row A8 holds at p = 1 too (the cost is convex piecewise linear in the cut, its minimum sits on a kink): for equal
+    sizes and uniform weights the equal-size HIP kernels (min over cyclic shifts, |.|^1) serve binary_search_circle(p=1)."""
+    g, u, v = _g3b_rows(golden, tag)
+    cost, _ = exact_shift.circular_ot_equal(u.numpy(), v.numpy(), p=1)
+    assert rel(cost, g[f"bsc_p1_{tag}_f64"]) < 1e-9
+    assert rel(cost, g[f"bsc_p1_{tag}_f32"]) < 2e-6
+
+
+# ---------------------------------------------------------------- G10: the notebooks' call shape (round 3)
+@pytest.mark.parametrize("target", ["cube", "sphere"])
+@pytest.mark.parametrize("p", [1, 2])
+def test_g10_notebook_shape_values_and_gradients(golden, target, p):
+    """Flow_cube.ipynb:1381 -- N = 1200, L = 100, un-normalised cube-surface evolving cloud: the restatement against the
+    real sliced_cost (value, per-slice costs, d loss / d evolving)."""
+    g = golden("g10_notebook_flow.npz")
+    x = T(g["source"]).clone().requires_grad_(True)
+    y = T(g["target" if target == "cube" else "sphere"])
+    U = T(g["U"])
+    val = ref_mirror.sliced_cost(x, y, U, p=p)
+    val.backward()
+    assert rel(val.detach().numpy(), g[f"loss_{target}_p{p}"]) < 2e-6
+    per = ref_mirror.per_slice_costs(x.detach(), y, U, p=p).numpy()
+    assert rel(per, g[f"per_slice_{target}_p{p}"]) < 1e-5
+    scale = np.abs(g[f"g_evolving_{target}_p{p}"]).max()
+    assert np.abs(x.grad.numpy() - g[f"g_evolving_{target}_p{p}"]).max() < 1e-4 * scale
+
+
+def test_g10_min_over_shifts_on_the_notebook_shape(golden):
+    g = golden("g10_notebook_flow.npz")
+    for target in ("target", "sphere"):
+        tag = "cube" if target == "target" else "sphere"
+        val = exact_shift.ssw_pair(g["source"], g[target], g["U"], p=2)
+        assert abs(val - float(g[f"loss_{tag}_p2"])) < 2e-6 * val
+
+
 # ---------------------------------------------------------------- G4: edges
 def test_g4_identical_clouds_are_exactly_zero(golden):
     g = golden("g4_edges.npz")

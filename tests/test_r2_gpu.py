@@ -598,8 +598,11 @@ def test_circle_level_values_and_gradients_against_the_cpu_oracle(shw, n, m, p, 
         wu, wv = torch.rand(n, generator=g) + 0.1, torch.rand(m, generator=g) + 0.1
         wu, wv = wu / wu.sum(), wv / wv.sum()
     ud, vd = u.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
-    cost = shw.binary_search_circle(ud, vd, u_weights=None if wu is None else wu.cuda(),
-                                    v_weights=None if wv is None else wv.cuda(), p=p)
+    # p = 1 here means the level-median formula = emd1D_circle (round 3: binary_search_circle(p=1) is the BISECTION, as in
+    # the reference; its tests are in test_r3_gpu.py)
+    entry = shw.emd1D_circle if p == 1 else shw.binary_search_circle
+    cost = entry(ud, vd, u_weights=None if wu is None else wu.cuda(),
+                 v_weights=None if wv is None else wv.cuda(), p=p)
     w = torch.tensor([1.0, -0.5, 2.0])
     (cost * w.cuda()).sum().backward()
     uc, vc = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
@@ -610,8 +613,8 @@ def test_circle_level_values_and_gradients_against_the_cpu_oracle(shw, n, m, p, 
     (ref * w).sum().backward()
     assert rel(cost.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
     with torch.no_grad():                # the loss-only kernels read coordinate rows too (p = 1 from 1025 merged atoms on:
-        plain = shw.binary_search_circle(u.cuda(), v.cuda(), u_weights=None if wu is None else wu.cuda(),   # cooperative)
-                                         v_weights=None if wv is None else wv.cuda(), p=p)
+        plain = entry(u.cuda(), v.cuda(), u_weights=None if wu is None else wu.cuda(),   # cooperative)
+                      v_weights=None if wv is None else wv.cuda(), p=p)
     assert rel(plain.cpu().numpy(), ref.detach().numpy()) < 2e-5
     loose = 0.2 if p == 1 else 2e-2
     # torch.rand coordinates sit on a 2^-24 grid: near-ties (and exact ties) are far more frequent than among projected

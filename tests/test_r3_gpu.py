@@ -1,0 +1,212 @@
+"""Round-3 GPU parity tests (`-m gpu`, MI355X): what VERDICT round 2 listed as unpinned, untested or non-deterministic.
+
+  G3b  `binary_search_circle` at its DEFAULT p = 1 (the bisection ending in Cost's p == 1 branch, max_spherical_sliced_w.py
+       :107-108, :117) against the real reference's outputs -- values and autograd gradients, equal / unequal sizes, weights;
+  G10  the notebooks' call shape (Flow_cube.ipynb:1381: N = 1200, L = 100, cube-surface evolving cloud, p in {1, 2},
+       value + per-slice costs + d/d evolving) against the real `sliced_cost`;
+  run-to-run bit-equality of every gradient the package produces (general path and Chamfer included);
+  the size classes between the powers of two (1200, 1280, 1500, 2000 ...) for loss and gradients.
+Tolerances are stated at each assertion.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shw():
+    import shw_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    shw_amd._lib.load()
+    return shw_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
+
+
+def unit_cloud(gen, *shape):
+    return torch.nn.functional.normalize(torch.randn(*shape, 3, generator=gen), dim=-1)
+
+
+def directions(gen, *shape):
+    return torch.linalg.qr(torch.randn(*shape, 3, 2, generator=gen))[0]
+
+
+# ------------------------------------------------------------------------------------------- G3b: bisection at p = 1
+G3B_PLAIN = ["64x64", "100x100", "256x256", "128x100", "96x96", "80x96", "1200x1200", "1000x750"]
+G3B_WITH_GRADS = ["64x64", "100x100", "256x256", "128x100"]
+G3B_WEIGHTED = ["96x96", "80x96", "1200x1200", "1000x750"]
+
+
+def g3b_rows(golden, tag):
+    g = golden("g3b_bisection_p1.npz")
+    src = g if f"u_{tag}" in g.files else golden("g3_circle.npz")
+    return g, dev(src[f"u_{tag}"]), dev(src[f"v_{tag}"])
+
+
+def sign_gradients_close(got, ref, max_wrong):
+    """Gradients of a p = 1 cost are sums of +-(CDF widths): piecewise CONSTANT in the coordinates.  An entry is either
+    right to rounding or off by a whole width; count the entries off by more than 2 % of the largest."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    wrong = int((np.abs(got - ref) > 2e-2 * np.abs(ref).max()).sum())
+    assert wrong <= max_wrong, (wrong, got.size)
+    return wrong
+
+
+@pytest.mark.parametrize("tag", G3B_PLAIN)
+def test_g3b_binary_search_circle_default_p_is_the_bisection(shw, golden, tag):
+    """VERDICT r2 missing 1 / ADVICE r2 (medium).  `binary_search_circle(u, v)` -- p defaults to 1 as at :117 -- against the
+    REAL reference's output on the same rows: 2e-5 per row against its float64 evaluation, 4e-5 against its fp32 one
+    (the reference's own fp32-vs-fp64 gap on these rows is <= 4.4e-7)."""
+    g, u, v = g3b_rows(golden, tag)
+    cost = shw.binary_search_circle(u, v)
+    assert tuple(cost.shape) == (u.shape[0],)
+    assert rel(cost.cpu().numpy(), g[f"bsc_p1_{tag}_f64"]) < 2e-5
+    assert rel(cost.cpu().numpy(), g[f"bsc_p1_{tag}_f32"]) < 4e-5
+    # and it is NOT the level-median value (up to 2.5 % away): emd1D_circle stays on that formula
+    median = shw.emd1D_circle(u, v)
+    assert rel(median.cpu().numpy(), g[f"bsc_p1_{tag}_f32"]) > 1e-4
+
+
+@pytest.mark.parametrize("tag", G3B_WITH_GRADS)
+def test_g3b_bisection_at_p1_gradients_against_reference_autograd(shw, golden, tag):
+    g, u, v = g3b_rows(golden, tag)
+    a, b = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    shw.binary_search_circle(a, b).sum().backward()
+    sign_gradients_close(a.grad.cpu().numpy(), g[f"bsc_p1_{tag}_gu"], max_wrong=2)
+    sign_gradients_close(b.grad.cpu().numpy(), g[f"bsc_p1_{tag}_gv"], max_wrong=2)
+
+
+@pytest.mark.parametrize("tag", G3B_WEIGHTED)
+def test_g3b_weighted_bisection_at_p1(shw, golden, tag):
+    """Weights and unequal sizes at p = 1 through the general kernel (PMODE 0 on |d|^1), values 2e-5 per row against the
+    reference's float64 run, gradients against its fp32 autograd."""
+    g, u, v = g3b_rows(golden, tag)
+    wu, wv = dev(g[f"wu_{tag}"]), dev(g[f"wv_{tag}"])
+    a, b = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    cost = shw.binary_search_circle(a, b, wu, wv, p=1)
+    cost.sum().backward()
+    assert rel(cost.detach().cpu().numpy(), g[f"bsc_p1_w_{tag}_f64"]) < 2e-5
+    assert rel(cost.detach().cpu().numpy(), g[f"bsc_p1_w_{tag}_f32"]) < 4e-5
+    n = u.shape[1]
+    sign_gradients_close(a.grad.cpu().numpy(), g[f"bsc_p1_w_{tag}_gu"], max_wrong=max(4, n // 100))
+    sign_gradients_close(b.grad.cpu().numpy(), g[f"bsc_p1_w_{tag}_gv"], max_wrong=max(4, n // 100))
+    with torch.no_grad():
+        assert rel(shw.binary_search_circle(u, v, wu, wv, p=1).cpu().numpy(), g[f"bsc_p1_w_{tag}_f64"]) < 2e-5
+
+
+@pytest.mark.parametrize("n,m,weighted", [(2048, 2048, False), (3000, 3000, False), (5000, 5000, False), (8192, 8192, False),
+                                          (700, 512, False), (2048, 1536, False), (2048, 2048, True), (1500, 900, True)])
+def test_bisection_at_p1_against_the_cpu_restatement(shw, n, m, weighted):
+    """Every kernel family that can serve binary_search_circle(p=1): equal sizes up to 8192 (one-wave, two-wave and
+    cooperative shift kernels on |.|^1), unequal sizes and weights (general kernel), against torch autograd of
+    oracle/ref_mirror.circular_ot_bisect (held to fixture G3b on the CPU)."""
+    from oracle import ref_mirror
+    gen = torch.Generator().manual_seed(5 * n + m + int(weighted))
+    rows = 3
+    u, v = torch.rand(rows, n, generator=gen), torch.rand(rows, m, generator=gen)
+    wu = wv = None
+    if weighted:
+        wu, wv = torch.rand(n, generator=gen) + 0.1, torch.rand(m, generator=gen) + 0.1
+        wu, wv = wu / wu.sum(), wv / wv.sum()
+    cu = None if wu is None else wu.cuda()
+    cv = None if wv is None else wv.cuda()
+    a, b = u.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    cost = shw.binary_search_circle(a, b, cu, cv)
+    cost.sum().backward()
+    ra, rb = u.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ref = ref_mirror.circular_ot_bisect(ra, rb, p=1, u_weights=wu, v_weights=wv)
+    ref.sum().backward()
+    ref64 = ref_mirror.circular_ot_bisect(u.double(), v.double(), p=1, u_weights=None if wu is None else wu.double(),
+                                          v_weights=None if wv is None else wv.double())
+    assert rel(cost.detach().cpu().numpy(), ref64.numpy()) < 2e-5
+    with torch.no_grad():
+        assert rel(shw.binary_search_circle(u.cuda(), v.cuda(), cu, cv).cpu().numpy(), ref64.numpy()) < 2e-5
+    sign_gradients_close(a.grad.cpu().numpy(), ra.grad.numpy(), max_wrong=max(4, (n + m) // 100))
+    sign_gradients_close(b.grad.cpu().numpy(), rb.grad.numpy(), max_wrong=max(4, (n + m) // 100))
+
+
+def test_emd1d_circle_refuses_other_powers(shw):
+    u = torch.rand(2, 16, device="cuda")
+    with pytest.raises(ValueError, match="level-median"):
+        shw.emd1D_circle(u, u, p=2)
+
+
+# ------------------------------------------------------------------------------------------- G10: the notebooks' shape
+@pytest.mark.parametrize("target", ["cube", "sphere"])
+@pytest.mark.parametrize("p", [1, 2])
+def test_g10_notebook_call_shape_against_the_real_sliced_cost(shw, golden, target, p):
+    """VERDICT r2 missing 2: the only live call site (Flow_cube.ipynb:1381) -- N = 1200 (:200), L = 100 (:747), an
+    un-normalised cube-surface evolving cloud, loss.backward().  Value 1e-5, per-slice 2e-5 (north_star / the suite's
+    per-slice bar), gradient through grad_close with the count of near-tie entries pinned at two swapped pairs."""
+    from helpers.compare import grad_close
+    g = golden("g10_notebook_flow.npz")
+    x = dev(g["source"]).requires_grad_(True)
+    y = dev(g["target" if target == "cube" else "sphere"]).requires_grad_(True)
+    U = dev(g["U"])
+    loss = shw.sliced_cost(x, y, U, p=p)
+    assert loss.dim() == 0
+    loss.backward()
+    assert rel(loss.item(), g[f"loss_{target}_p{p}"]) < 1e-5
+    _, per, _ = shw.ssw_pair_losses(x.detach()[None], y.detach()[None], U, p=p, return_slices=True)
+    assert rel(per[0].cpu().numpy(), g[f"per_slice_{target}_p{p}"]) < 2e-5
+    loose = 0.2 if p == 1 else 2e-2
+    grad_close(x.grad.cpu().numpy(), g[f"g_evolving_{target}_p{p}"], loose=loose, max_outside=12)
+    grad_close(y.grad.cpu().numpy(), g[f"g_target_{target}_p{p}"], loose=loose, max_outside=12)
+
+
+@pytest.mark.parametrize("p", [1, 2])
+def test_g10_five_adam_steps_of_the_notebook_flow(shw, golden, p):
+    """The notebook's loop (:1372-1395): zero_grad, loss, backward(retain_graph=True), Adam step -- five steps on the
+    stored per-step directions.  Loss trace 1e-4 per step (Adam's first steps move every coordinate by ~lr whatever the
+    gradient's size, so fp32 noise in tiny gradient entries shows up in the next loss at the 1e-5 level), evolved cloud
+    within 2 lr of the reference's for all but a handful of coordinates."""
+    g = golden("g10_notebook_flow.npz")
+    lr = float(g["lr"])
+    evolving = dev(g["source"]).requires_grad_(True)
+    target = dev(g["target"])
+    U_steps = dev(g["U_steps"])
+    opt = torch.optim.Adam([evolving], lr=lr, betas=(0.9, 0.999))
+    trace = []
+    for i in range(U_steps.shape[0]):
+        opt.zero_grad()
+        loss = shw.sliced_cost(evolving, target, U_steps[i], p=p)
+        loss.backward(retain_graph=True)
+        opt.step()
+        trace.append(loss.item())
+    assert rel(trace, g[f"flow_trace_p{p}"]) < 1e-4
+    moved = np.abs(evolving.detach().cpu().numpy() - g[f"flow_evolved_p{p}"])
+    assert (moved > 2 * lr).sum() <= 8 and np.median(moved) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- bench.py starts its own ranks
+def test_bench_self_launch_path_prints_one_json_line():
+    """`python bench.py --gpus N` (N > 1) must start its N ranks itself.  One GPU per box here, so the
+    same code path is forced at N = 1 (SHW_BENCH_FORCE_SPAWN=1): the parent starts torch.distributed.run with one rank as
+    a CHILD process (RCCL communicator, the 514-float all-reduce per step), relays rank 0's line and its exit status."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SHW_BENCH_FORCE_SPAWN="1")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = res.stdout.strip().split("\n")
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and "roofline" in d
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert "starting 1 ranks" in res.stderr
