@@ -15,8 +15,16 @@
 //
 // This is the compatibility path (~10x the work of the equal-size kernel): the trainers' "different
 // source / target density" option (train_W_COS.py:292-293,334-336) and the u_weights / v_weights
-// arguments (:289) land here.  Gradients are accumulated per sorted atom with LDS float atomics (a
-// handful of terms per atom; their order, hence the last bit, may vary between runs).
+// arguments (:289) land here.
+//
+// Round 3: W wavefronts of one workgroup share a slice (W = 2 from 1024 points on, 4 at 4096).  The LDS arrays are the
+// slice's, so W waves per slice put W times the waves on a CU without another byte of LDS (round 2 ran ONE wave per
+// SIMD at n = 2048 with weights: 7.5 clocks per instruction of a dependent chain).  Wave 0 sorts the source while wave 1
+// sorts the target; every evaluation of the solve is split by atoms (thread t of the slice owns sorted atoms
+// [t AP, (t+1) AP), AP = EPT / W) and its partial sums are added in wave order through LDS, so all waves take the same
+// decisions.  Gradients are OWNER-COMPUTED: every sorted atom's coefficient is accumulated in registers by one thread
+// that walks the merged CDF grid over the atom's own mass interval, and written once -- no zero fill, no float
+// atomics, bit-identical from run to run like the reference's autograd on the CPU.
 #include "bin_sort_idx.hpp"
 #include "ssw_common.hpp"
 
@@ -52,6 +60,40 @@ struct GeneralArgs {
   // instead of a second pair of sorts at the gradient kernel's low occupancy.
   int idx_handoff;
 };
+
+// The W waves of the workgroup that owns a slice.  sum(): wave-uniform partial sums -> sums over the slice, added in wave
+// order (every wave gets the same bits, so control flow that depends on them stays uniform over the workgroup).  One
+// barrier per call: the slots alternate between two parities, and a wave can only be one call ahead of another.
+template <int W>
+struct SliceTeam {
+  float* red;               // [2 parities][W][4] floats
+  int wave;
+  int parity;
+  template <int K>
+  __device__ __forceinline__ void sum(float (&v)[K], int lane) {
+    static_assert(K <= 4, "four sums per call");
+    if constexpr (W > 1) {
+      float* slot = red + parity * (4 * W);
+      parity ^= 1;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) slot[wave * 4 + k] = v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < W; ++q) acc += slot[q * 4 + k];
+        v[k] = as_f(__builtin_amdgcn_readfirstlane(as_i(acc)));
+      }
+    }
+  }
+};
+constexpr int kTeamFloats = 48;   // two parities of four waves' sums + the means and the tail coefficient
+
+// waves per slice by size class: the evaluations split by atoms, the two sorts take one wave each
+constexpr int general_waves(int ept) { return ept >= 64 ? 4 : (ept >= 16 ? 2 : 1); }
 
 // one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout.
 // UNIFORM (no weights given, the reference's default 1/count): the CDF is (i+1)/count -- no array -- and every
@@ -481,33 +523,35 @@ struct Rotated {
 template <int PMODE>
 __device__ __forceinline__ float powp(float d, float p, int p_int) { return pow_abs<PMODE>(d, p, p_int); }
 
-// one-sided derivatives of the cost w.r.t. theta (reference dCost, :50-63), wave-uniform results
-template <int EPT, int PMODE, bool UNIFORM>
-__device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, float p, int p_int,
-                           float& d_plus, float& d_minus) {
+// one-sided derivatives of the cost w.r.t. theta (reference dCost, :50-63), uniform over the slice's waves.
+// tid: index of the thread among the 64 W threads of the slice; it owns target atoms [tid AP, (tid+1) AP), AP = EPT / W.
+template <int EPT, int PMODE, bool UNIFORM, int W>
+__device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, int tid, float p,
+                           int p_int, SliceTeam<W>& team, float& d_plus, float& d_minus) {
+  constexpr int AP = EPT / W;
   Rotated<EPT, UNIFORM> R;
   R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   float sp = 0.f, sm = 0.f;
   constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
-  constexpr int NA = EPT < NA_MAX ? EPT : NA_MAX;
-  int walk_ptr = 0;                                          // weighted: rank of the lane's previous atom
+  constexpr int NA = AP < NA_MAX ? AP : NA_MAX;
+  int walk_ptr = 0;                                          // weighted: rank of the thread's previous atom
   float walk_prev = 0.f;
   if constexpr (!UNIFORM) {
     float c0, p0;
-    R.atom(min(lane * EPT, m - 1), c0, p0);
+    R.atom(min(tid * AP, m - 1), c0, p0);
     walk_ptr = lower_bound_arr<EPT>(S.cdf, n, c0);
     walk_prev = c0;
   }
 #pragma nounroll
-  for (int r0 = 0; r0 < EPT; r0 += NA) {
+  for (int r0 = 0; r0 < AP; r0 += NA) {
     // NA + 1 consecutive atoms: atom a and its successor a + 1 (the atom after the last one is atom 0; indices
     // past the end repeat the last atom and are masked below)
     float wc[NA + 1], wp[NA + 1];
     int wj[NA + 1];
 #pragma unroll
     for (int a = 0; a <= NA; ++a) {
-      const int q = lane * EPT + r0 + a;
+      const int q = tid * AP + r0 + a;
       wj[a] = q < m ? q : (q == m ? 0 : m - 1);
       R.atom(wj[a], wc[a], wp[a]);
     }
@@ -524,7 +568,7 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
     } else {
       bool alive[NA];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) alive[a] = (lane * EPT + r0 + a) < m;
+      for (int a = 0; a < NA; ++a) alive[a] = (tid * AP + r0 + a) < m;
       walk_lower_bounds2<EPT, NA>(S.cdf, n, cdf, alive, walk_prev, walk_ptr, lt, le);
     }
     const float v0 = S.v(0);
@@ -535,28 +579,31 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
       // atom one turn later (the second extension, level c0 + 1, cannot be reached: cdf <= 1); unconditional read
       const float sv = S.v(min(le[a], n - 1));
       const float ar = le[a] < n ? sv : v0 + 1.f;
-      const bool live = (lane * EPT + r0 + a) < m;
+      const bool live = (tid * AP + r0 + a) < m;
       const float tp = powp<PMODE>(al - npos[a], p, p_int) - powp<PMODE>(al - pos[a], p, p_int);
       const float tm = powp<PMODE>(ar - npos[a], p, p_int) - powp<PMODE>(ar - pos[a], p, p_int);
       sp += live ? tp : 0.f;
       sm += live ? tm : 0.f;
     }
   }
-  d_plus = wave_sum_uniform(sp, lane);
-  d_minus = wave_sum_uniform(sm, lane);
+  float sums[2] = {wave_sum_uniform(sp, lane), wave_sum_uniform(sm, lane)};
+  team.sum(sums, lane);
+  d_plus = sums[0];
+  d_minus = sums[1];
 }
 
 // cut_slopes for weighted clouds as C interleaved walks (see walk_lower_bounds2): chain c covers atoms
-// [c * EPT/C, (c+1) * EPT/C) of the lane, the C chains advance together -- 4 C independent reads per round, EPT/C
+// [c * AP/C, (c+1) * AP/C) of the thread's AP atoms, the C chains advance together -- 4 C independent reads per round, EPT/C
 // rounds per evaluation -- and each chain's first rank is carried from one evaluation of the solve to the next
 // (`anchor`; warm = false: binary search): the cut moves by less than a level spacing between late evaluations, so
 // the carried rank is put right by one backward and one forward round instead of a 12-probe search.
-template <int EPT, int PMODE, int C>
-__device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false>& T, float theta, int lane, float p,
-                                int p_int, float& d_plus, float& d_minus, int (&anchor)[C], bool warm,
+template <int EPT, int PMODE, int C, int W>
+__device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false>& T, float theta, int lane, int tid, float p,
+                                int p_int, SliceTeam<W>& team, float& d_plus, float& d_minus, int (&anchor)[C], bool warm,
                                 float& cost_scale) {
-  constexpr int LEN = EPT / C;
-  static_assert(EPT % C == 0, "chains of equal length");
+  constexpr int AP = EPT / W;                                // atoms of the thread: [tid AP, (tid+1) AP)
+  constexpr int LEN = AP / C;
+  static_assert(AP % C == 0, "chains of equal length");
   Rotated<EPT, false> R;
   R.set(T, theta, lane);
   const int n = S.count, m = T.count;
@@ -571,7 +618,7 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     int j;
-    atom_q(lane * EPT + c * LEN, own_c[c], own_p[c], j);
+    atom_q(tid * AP + c * LEN, own_c[c], own_p[c], j);
     prev[c] = own_c[c];
     ptr[c] = min(max(anchor[c], 0), n);
     float bc, bp;                                            // mass of the chain's first atom: level step from its predecessor
@@ -612,7 +659,7 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
     bool live[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const int q = lane * EPT + c * LEN + i;
+      const int q = tid * AP + c * LEN + i;
       live[c] = q < m;
       pos[c] = own_p[c];
       k[c] = live[c] ? own_c[c] : prev[c];
@@ -644,48 +691,51 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
       sc += live[c] ? w[c] * powp<PMODE>(al - pos[c], p, p_int) : 0.f;
     }
   }
-  d_plus = wave_sum_uniform(sp, lane);
-  d_minus = wave_sum_uniform(sm, lane);
-  // the cost with every target atom sent whole to the source quantile at its level: the size of the cost, for the
+  // sc: the cost with every target atom sent whole to the source quantile at its level: the size of the cost, for the
   // solve's exit test
-  cost_scale = wave_sum_uniform(sc, lane);
+  float sums[3] = {wave_sum_uniform(sp, lane), wave_sum_uniform(sm, lane), wave_sum_uniform(sc, lane)};
+  team.sum(sums, lane);
+  d_plus = sums[0];
+  d_minus = sums[1];
+  cost_scale = sums[2];
 }
 
-// transport cost at a fixed cut (reference Cost, :94-112).  GRAD: also accumulates
-// d cost / d (sorted source atom) into gs and d cost / d (sorted target atom) into gt.
-template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
-__device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, float p, int p_int,
-                          float* gs, float* gt) {
+// transport cost at a fixed cut (reference Cost, :94-112), uniform over the slice's waves.  Thread tid evaluates the grid
+// points of source atoms and of target atoms [tid AP, (tid+1) AP).
+template <int EPT, int PMODE, bool UNIFORM, int W>
+__device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, int tid, float p,
+                          int p_int, SliceTeam<W>& team) {
+  constexpr int AP = EPT / W;
   Rotated<EPT, UNIFORM> R;
   R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   float acc = 0.f;
   constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
-  constexpr int NA = EPT < NA_MAX ? EPT : NA_MAX;
-  int walk_cnt = 0, walk_ptr = 0;                            // weighted: ranks of the lane's previous atoms
+  constexpr int NA = AP < NA_MAX ? AP : NA_MAX;
+  int walk_cnt = 0, walk_ptr = 0;                            // weighted: ranks of the thread's previous atoms
   float walk_prev = 0.f;
   if constexpr (!UNIFORM) {
-    const float k1[1] = {S.c(min(lane * EPT, n - 1))};
+    const float k1[1] = {S.c(min(tid * AP, n - 1))};
     int c1[1];
     R.template below_batch<1>(k1, c1);
     walk_cnt = c1[0];
     float c0, p0;
-    R.atom(min(lane * EPT, m - 1), c0, p0);
+    R.atom(min(tid * AP, m - 1), c0, p0);
     walk_ptr = lower_bound_arr<EPT>(S.cdf, n, c0);
     walk_prev = c0;
   }
 #pragma nounroll
-  for (int r0 = 0; r0 < EPT; r0 += NA) {
+  for (int r0 = 0; r0 < AP; r0 += NA) {
     {  // grid points = source CDF levels A_e
       float g[NA];
       int cnt[NA];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) g[a] = S.c(min(lane * EPT + r0 + a, n - 1));
+      for (int a = 0; a < NA; ++a) g[a] = S.c(min(tid * AP + r0 + a, n - 1));
       if constexpr (UNIFORM) R.template below_batch<NA>(g, cnt);   // rotated target atom active at g
       else R.template below_walk<NA>(g, walk_cnt, cnt);
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
-        const int e = lane * EPT + r0 + a;
+        const int e = tid * AP + r0 + a;
         const bool live = e < n;
         const int ec = min(e, n - 1);
         const float b = R.pos_at(min(cnt[a], m));
@@ -694,21 +744,13 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
         const float width = g[a] - fmaxf(prev_a, prev_c);
         const float d = S.v(ec) - b;
         acc += live ? width * powp<PMODE>(d, p, p_int) : 0.f;
-        if constexpr (GRAD) {
-          if (live) {
-            const float w = width * dpow_abs<PMODE>(d, p, p_int);
-            const int jt = (cnt[a] >= m) ? R.start : R.source_index(cnt[a]);
-            SHW_LDS_ADD(&gs[lds_slot<EPT>(e)], w);
-            SHW_LDS_ADD(&gt[lds_slot<EPT>(jt)], -w);
-          }
-        }
       }
     }
     {  // grid points = shifted target CDF levels C_e
       float g[NA], b[NA];
       int lt[NA], le[NA];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) R.atom(min(lane * EPT + r0 + a, m - 1), g[a], b[a]);
+      for (int a = 0; a < NA; ++a) R.atom(min(tid * AP + r0 + a, m - 1), g[a], b[a]);
       if constexpr (UNIFORM) {
         lower_bounds2<EPT, UNIFORM, NA>(S, g, lt, le);
       } else if constexpr (general_walks<EPT, UNIFORM>()) {  // window reads (the rows under the source CDF exist)
@@ -730,7 +772,7 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
       }
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
-        const int e = lane * EPT + r0 + a;
+        const int e = tid * AP + r0 + a;
         const bool live = e < m;
         const int ec = min(e, m - 1);
         const int rho = ec >= R.start ? ec - R.start : ec - R.start + m;
@@ -742,17 +784,124 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
         const float width = g[a] - fmaxf(prev_a, prev_c);
         const float d = av - b[a];
         acc += live ? width * powp<PMODE>(d, p, p_int) : 0.f;
-        if constexpr (GRAD) {
-          if (live) {
-            const float w = width * dpow_abs<PMODE>(d, p, p_int);
-            SHW_LDS_ADD(&gs[lds_slot<EPT>(il)], w);
-            SHW_LDS_ADD(&gt[lds_slot<EPT>(e)], -w);
-          }
-        }
       }
     }
   }
-  return wave_sum_uniform(acc, lane);
+  float sums[1] = {wave_sum_uniform(acc, lane)};
+  team.sum(sums, lane);
+  return sums[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient of Cost at the (detached) cut, OWNER-COMPUTED (round 3).  The merged CDF grid of Cost (:95-105) cuts [0, 1]
+// into segments; on each one source atom i and one rotated target atom rho are active, and the segment adds
+// width * |u_i - v_rho|^p to the cost, width * d|D|^p/dD to the coefficient of atom i and its negative to atom rho's.
+// Round 2 accumulated both with LDS float atomics (sum order, hence the last bits, varied between runs).  Here every
+// atom has ONE owner that walks the segments of the atom's own mass interval -- a two-pointer merge of its interval
+// with the other cloud's levels, one segment per step -- accumulates in a register and writes the coefficient once:
+//   walk_source_atoms : thread tid owns sorted source atoms [tid AP, (tid+1) AP); atom e's interval is
+//                       (A_{e-1}, A_e], crossed by the rotated target levels C_rho inside it.  Also returns the
+//                       thread's share of the cost (every segment belongs to exactly one source atom; the segments
+//                       above the last source level -- rounding -- go to the last atom like the reference's clip).
+//   walk_target_atoms : thread tid owns ROTATED target atoms [tid AP, (tid+1) AP) (the rotated order is the order of
+//                       their levels); the owner of the last one also walks the tail (C_{m-1}, 1], where the active
+//                       target atom is the appended copy of the first rotated atom one turn later (:48, :103): its
+//                       coefficient belongs to that first atom and is handed over in `tail` (added in a fixed order).
+// A step costs ~20 VALU + 3 LDS reads; a thread takes ~2 AP steps (its atoms + the foreign levels in its range), and
+// threads are balanced because equal counts of atoms hold nearly equal mass.  Ties (a source level equal to a target
+// level) advance the source first; the leftover segment has width 0 -- the reference's merged grid gives the duplicate
+// grid point a zero delta too.
+// ---------------------------------------------------------------------------------------------
+template <int EPT, int PMODE, bool UNIFORM, int W>
+__device__ float walk_source_atoms(const Side<EPT, UNIFORM>& S, const Rotated<EPT, UNIFORM>& R, int tid, float p, int p_int,
+                                   float* gs) {
+  constexpr int AP = EPT / W;
+  const int n = S.count, m = R.t.count;
+  const float inf = __builtin_inff();
+  int e = tid * AP;
+  const int e_end = min(e + AP, n);
+  bool active = e < e_end;
+  const int e0 = min(e, n - 1);
+  float a_prev = e0 > 0 ? S.c(e0 - 1) : 0.f;
+  int rho = active ? (e0 > 0 ? R.below(a_prev) : 0) : m;
+  float c_prev = rho > 0 ? R.cdf_at(min(rho, m) - 1) : 0.f;
+  float a = S.c(e0), u = S.v(e0);
+  float c = rho < m ? R.cdf_at(rho) : inf;
+  float pos = R.pos_at(min(rho, m));
+  float acc = 0.f, cost = 0.f;
+  bool extended = false;                                     // the last source atom also takes the levels above A_{n-1}
+  for (int guard = 0; guard < 2 * kWave * EPT + 8; ++guard) {
+    if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+    if (active) {
+      const float end = fminf(a, c);                         // (+inf: no level left on either side -- nothing to add)
+      const float width = end < inf ? fmaxf(end - fmaxf(a_prev, c_prev), 0.f) : 0.f;
+      const float d = u - pos;
+      acc = fmaf(width, dpow_abs<PMODE>(d, p, p_int), acc);
+      cost = fmaf(width, powp<PMODE>(d, p, p_int), cost);
+      if (c < a) {                                           // the segment ended on a target level: next target atom
+        c_prev = c;
+        ++rho;
+        c = rho < m ? R.cdf_at(rho) : inf;
+        pos = R.pos_at(min(rho, m));
+      } else if (e == n - 1 && !extended) {                  // (u_index.clip(0, n-1), :101)
+        extended = true;
+        a_prev = a;
+        a = inf;
+      } else {                                               // the atom's interval is done: its coefficient, once
+        gs[lds_slot<EPT>(e)] = acc;
+        acc = 0.f;
+        a_prev = a;
+        ++e;
+        active = e < e_end;
+        const int ec = min(e, n - 1);
+        a = S.c(ec);
+        u = S.v(ec);
+      }
+    }
+  }
+  return cost;
+}
+
+template <int EPT, int PMODE, bool UNIFORM, int W>
+__device__ void walk_target_atoms(const Side<EPT, UNIFORM>& S, const Rotated<EPT, UNIFORM>& R, int tid, float p, int p_int,
+                                  float* gt, float* tail) {
+  constexpr int AP = EPT / W;
+  const int n = S.count, m = R.t.count;
+  const float inf = __builtin_inff();
+  int rho = tid * AP;
+  const int rho_end = min(rho + AP, m);
+  const bool owns_tail = (rho < m) && (rho_end == m);        // owner of the last rotated atom
+  bool active = rho < rho_end;
+  const int r0 = min(rho, m - 1);
+  float c_prev = r0 > 0 ? R.cdf_at(r0 - 1) : 0.f;
+  int i = active ? (r0 > 0 ? S.below(c_prev, true) : 0) : n;
+  float a_prev = i > 0 ? S.c(min(i, n) - 1) : 0.f;
+  float a = i < n ? S.c(i) : inf, u = S.v(min(i, n - 1));
+  float c = R.cdf_at(r0), pos = R.pos_at(r0);
+  float acc = 0.f;
+  for (int guard = 0; guard < 2 * kWave * EPT + 8; ++guard) {
+    if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+    if (active) {
+      const float end = fminf(a, c);                         // (+inf: the tail beyond the last source level is empty)
+      const float width = end < inf ? fmaxf(end - fmaxf(a_prev, c_prev), 0.f) : 0.f;
+      acc = fmaf(width, dpow_abs<PMODE>(u - pos, p, p_int), acc);
+      if (i < n && a <= c) {                                 // the segment ended on a source level: next source atom
+        a_prev = a;
+        ++i;
+        a = i < n ? S.c(i) : inf;
+        u = S.v(min(i, n - 1));
+      } else {                                               // the atom's interval is done
+        if (rho < m) gt[lds_slot<EPT>(R.source_index(rho))] = -acc;
+        else *tail = -acc;                                   // the appended copy: belongs to the first rotated atom
+        acc = 0.f;
+        c_prev = c;
+        ++rho;
+        active = rho < rho_end || (owns_tail && rho == m);
+        c = rho < m ? R.cdf_at(rho) : inf;
+        pos = R.pos_at(min(rho, m));
+      }
+    }
+  }
 }
 
 // inclusive prefix sum over the wave's sorted positions lane*EPT + r  (the CDF, :169-170)
@@ -772,118 +921,121 @@ __device__ __forceinline__ void sorted_cdf(float (&w)[EPT], int lane) {
   for (int r = 0; r < EPT; ++r) w[r] += offset;
 }
 
-// project, sort (with indices), gather weights and build the CDFs of both clouds of slice s; leaves the sorted
-// values / CDFs in LDS and the sorted->original index maps in registers
+// project, sort (with indices), gather weights and build the CDF of ONE cloud of slice s (which = 0: target, 1: source);
+// leaves the sorted values / CDF in LDS (dval, dcdf) and the sorted->original index map in registers.  `scratch` is a row
+// for the coordinates by original index (it may be dval itself: the gather out of it is complete before the sorted values
+// are written, LDS operations of a wave execute in order), `counters` 32 EPT words for the distribution sort.
 template <int EPT, bool UNIFORM = false>
-__device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int lane, float* s_val, float* s_cdf,
-                                              float* t_val, float* t_cdf, float* scratch, int (&sidx)[EPT],
-                                              int (&tidx)[EPT], float& mean_s, float& mean_t,
-                                              unsigned* counters = nullptr) {
+__device__ __forceinline__ void prepare_one(const GeneralArgs& G, int s, int lane, int which, float* dval, float* dcdf,
+                                            float* scratch, unsigned* counters, int (&idx)[EPT], float& mean_out) {
   const SswArgs& A = G.base;
   const int b = s / A.slices, l = s - b * A.slices;
   const int n = A.n, m = A.m;
   float U[6];
   load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
+  const float* X = which == 0 ? A.xt + (long)b * m * A.pstride : A.xs + (long)b * n * A.pstride;
+  const int count = which == 0 ? m : n;
+  const float* Wt = which == 0 ? G.wv : G.wu;
+  const long wstride = which == 0 ? G.wv_pair_stride : G.wu_pair_stride;
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  float val[EPT];
+  // weighted, >= 8 atoms per lane: the distribution sort of bin_sort_idx.hpp (32 EPT counters beside the staging
+  // row).  Without weights the one-wave kernel ran two waves per SIMD on 248 registers and the distribution sort's extra
+  // live words spilled (measured in round 2: 2.1 -> 3.3 ms at n = 2048, m = 1536): it keeps the network.
+  float part;
+  if constexpr (EPT >= 8 && !UNIFORM) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
+  else part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
+  float mean = 0.f;                                        // mass-weighted mean coordinate (first guess of the cut)
+  if constexpr (UNIFORM) {
+    mean = wave_sum_uniform(part, lane) / (float)count;                                 // CDF = (i+1)/count in closed form: no array
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) dval[r * kWave + lane] = val[r];
+  } else {
+    float w[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int e = lane * EPT + r;
+      const bool live = e < count;
+      w[r] = !live ? 0.f : (Wt ? Wt[(long)b * wstride + idx[r]] : 1.f / (float)count);
+      mean += live ? w[r] * val[r] : 0.f;
+    }
+    mean = wave_sum_uniform(mean, lane);
+    sorted_cdf<EPT>(w, lane);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {                        // sorted position lane*EPT + r -> slot r*64 + lane
+      dval[r * kWave + lane] = val[r];
+      dcdf[r * kWave + lane] = (lane * EPT + r < count) ? w[r] : __builtin_inff();   // (window reads count on it)
+    }
+  }
+  mean_out = mean;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// both clouds by ONE wave, the target first (the p = 1 kernels and the classes below 1024 points)
+template <int EPT, bool UNIFORM = false>
+__device__ __forceinline__ void prepare_sides(const GeneralArgs& G, int s, int lane, float* s_val, float* s_cdf,
+                                              float* t_val, float* t_cdf, float* scratch, int (&sidx)[EPT],
+                                              int (&tidx)[EPT], float& mean_s, float& mean_t,
+                                              unsigned* counters = nullptr) {
+  int idx[EPT];
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {                  // 0: target, 1: source
-    const float* X = which == 0 ? A.xt + (long)b * m * A.pstride : A.xs + (long)b * n * A.pstride;
-    const int count = which == 0 ? m : n;
-    const float* W = which == 0 ? G.wv : G.wu;
-    const long wstride = which == 0 ? G.wv_pair_stride : G.wu_pair_stride;
-    float* dval = which == 0 ? t_val : s_val;
-    float* dcdf = which == 0 ? t_cdf : s_cdf;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    float val[EPT];
-    int idx[EPT];
-    // weighted, >= 8 atoms per lane: the distribution sort of bin_sort_idx.hpp (32 EPT counters beside the staging
-    // row).  Without weights the kernel runs two waves per SIMD on 248 registers and the distribution sort's extra
-    // live words would spill (measured: 2.1 -> 3.3 ms at n = 2048, m = 1536): it keeps the network.
-    float part;
-    if constexpr (EPT >= 8 && !UNIFORM) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
-    else part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
-    float mean = 0.f;                                        // mass-weighted mean coordinate (first guess of the cut)
-    if constexpr (UNIFORM) {
-      mean = wave_sum_uniform(part, lane) / (float)count;                                 // CDF = (i+1)/count in closed form: no array
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) dval[r * kWave + lane] = val[r];
-    } else {
-      float w[EPT];
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) {
-        const int e = lane * EPT + r;
-        const bool live = e < count;
-        w[r] = !live ? 0.f : (W ? W[(long)b * wstride + idx[r]] : 1.f / (float)count);
-        mean += live ? w[r] * val[r] : 0.f;
-      }
-      mean = wave_sum_uniform(mean, lane);
-      sorted_cdf<EPT>(w, lane);
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) {                        // sorted position lane*EPT + r -> slot r*64 + lane
-        dval[r * kWave + lane] = val[r];
-        dcdf[r * kWave + lane] = (lane * EPT + r < count) ? w[r] : __builtin_inff();   // (window reads count on it)
-      }
-    }
-    if (which == 0) mean_t = mean; else mean_s = mean;
+    float mean;
+    prepare_one<EPT, UNIFORM>(G, s, lane, which, which == 0 ? t_val : s_val, which == 0 ? t_cdf : s_cdf, scratch, counters,
+                              idx, mean);
     if (which == 0) {
+      mean_t = mean;
 #pragma unroll
       for (int r = 0; r < EPT; ++r) tidx[r] = idx[r];
     } else {
+      mean_s = mean;
 #pragma unroll
       for (int r = 0; r < EPT; ++r) sidx[r] = idx[r];
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// gradient launch with index hand-off: sorted coordinates of both clouds from the permutations the solve launch
-// left in the coefficient rows (same projection arithmetic as load_coords, so the values are bit-identical to
-// the ones that were sorted)
+// gradient launch with index hand-off: sorted coordinates of one cloud (which = 0: target, 1: source) from the permutation
+// the solve launch left in the coefficient rows (same projection arithmetic as load_coords, so the values are
+// bit-identical to the ones that were sorted)
 template <int EPT>
-__device__ __forceinline__ void prepare_from_indices(const GeneralArgs& G, int s, int lane, float* s_val, float* t_val,
-                                                     int (&sidx)[EPT], int (&tidx)[EPT]) {
+__device__ __forceinline__ void prepare_one_from_indices(const GeneralArgs& G, int s, int lane, int which, float* dval,
+                                                         int (&idx)[EPT]) {
   const SswArgs& A = G.base;
   const int b = s / A.slices, l = s - b * A.slices;
   float U[6];
   load_frame(A.dirs, (long)b * A.u_pair_stride + (long)l * 6, U);   // (3,2) row-major: U[2*d + k]
-#pragma nounroll
-  for (int which = 0; which < 2; ++which) {
-    const int count = which == 0 ? A.m : A.n;
-    const float* X = which == 0 ? A.xt + (long)b * count * A.pstride : A.xs + (long)b * count * A.pstride;
-    const unsigned short* perm = reinterpret_cast<const unsigned short*>(
-        which == 0 ? A.coef_t + (long)s * A.m : A.coef_s + (long)s * A.n);
-    float* dval = which == 0 ? t_val : s_val;
-    int idx[EPT];
+  const int count = which == 0 ? A.m : A.n;
+  const float* X = which == 0 ? A.xt + (long)b * count * A.pstride : A.xs + (long)b * count * A.pstride;
+  const unsigned short* perm = reinterpret_cast<const unsigned short*>(
+      which == 0 ? A.coef_t + (long)s * A.m : A.coef_s + (long)s * A.n);
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int e = lane * EPT + r;
-      idx[r] = e < count ? (int)perm[min(e, count - 1)] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int e = lane * EPT + r;
-      const float px = X[3 * idx[r]], py = X[3 * idx[r] + 1], pz = X[3 * idx[r] + 2];
-      const float a = fmaf(pz, U[4], fmaf(py, U[2], fmaf(px, U[0], 0.f)));
-      const float bb = fmaf(pz, U[5], fmaf(py, U[3], fmaf(px, U[1], 0.f)));
-      dval[r * kWave + lane] = e < count ? circle_coord(a, bb) : __builtin_inff();
-    }
-    if (which == 0) {
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) tidx[r] = idx[r];
-    } else {
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) sidx[r] = idx[r];
-    }
-    __builtin_amdgcn_wave_barrier();
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    idx[r] = e < count ? (int)perm[min(e, count - 1)] : 0;
   }
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = lane * EPT + r;
+    const float px = X[3 * idx[r]], py = X[3 * idx[r] + 1], pz = X[3 * idx[r] + 2];
+    const float a = fmaf(pz, U[4], fmaf(py, U[2], fmaf(px, U[0], 0.f)));
+    const float bb = fmaf(pz, U[5], fmaf(py, U[3], fmaf(px, U[1], 0.f)));
+    dval[r * kWave + lane] = e < count ? circle_coord(a, bb) : __builtin_inff();
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
-template <int EPT, int PMODE, bool GRAD, bool UNIFORM>
-__global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
+template <int EPT, int PMODE, bool GRAD, bool UNIFORM, int W>
+__global__ __launch_bounds__(64 * W, W > 1 ? 2 : 1) void ssw_general_kernel(GeneralArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave;
+  constexpr int AP = EPT / W;                                // sorted atoms per thread in the evaluations
+  static_assert(EPT % W == 0 && AP >= 1, "atoms split evenly over the slice's threads");
   const SswArgs& A = G.base;
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tid = wave * kWave + lane;                       // thread of the slice: owns sorted atoms [tid AP, (tid+1) AP)
   // rows: sorted values of both clouds, their CDFs (weighted only), coordinates by original index (later the
   // source gradient row), target gradient row (GRAD only)
   float* s_val = lds;
@@ -891,40 +1043,91 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
   constexpr int EXT = general_ext_floats<EPT, UNIFORM>();     // window rows under the source CDF (fill_walk_ext)
   float* s_cdf = UNIFORM ? nullptr : lds + 2 * ROW;
   float* t_cdf = UNIFORM ? nullptr : lds + 3 * ROW + EXT;
-  // (loss only: the coordinates-by-original-index row of the sort shares the source row -- the gather out of it
-  //  is complete before the sorted values are written, LDS operations of a wave execute in order)
-  float* scratch = GRAD ? lds + (UNIFORM ? 2 : 4) * ROW + EXT : s_val;
-  float* gt = scratch + ROW;                                 // GRAD only
+  float* grad_rows = lds + (UNIFORM ? 2 : 4) * ROW + EXT;    // GRAD only: two rows of coefficients by sorted position
+  float* gs = grad_rows;
+  float* gt = grad_rows + ROW;
+  float* team_mem = lds + ((UNIFORM ? 2 : 4) + (GRAD ? 2 : 0)) * ROW + EXT;
+  SliceTeam<W> team{team_mem, wave, 0};
+  float* shared = team_mem + 8 * W;                          // [0], [1]: the two mean coordinates; [2]: the tail coefficient
 
   const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
-  if (s >= A.pairs * A.slices) return;
+  if (s >= A.pairs * A.slices) return;                       // (uniform over the workgroup)
   const int n = A.n, m = A.m;
-  int sidx[EPT], tidx[EPT];
+  // sorted -> original index maps.  One wave per slice: [0] target, [1] source.  W waves: wave 0 sorts the source and
+  // wave 1 the target at the same time, each keeps its own cloud's map in [0].
+  constexpr int NI = W == 1 ? 2 : 1;
+  int oidx[NI][EPT];
   float mean_s = 0.f, mean_t = 0.f;
   float handed_cut = 0.f;
-  if (GRAD && UNIFORM && G.idx_handoff) {
-    handed_cut = A.coef_t[(long)s * m + (m - 1)];            // read before the rows are reused
-    prepare_from_indices<EPT>(G, s, lane, s_val, t_val, sidx, tidx);
+  const bool from_indices = GRAD && UNIFORM && G.idx_handoff;
+  if (from_indices) handed_cut = A.coef_t[(long)s * m + (m - 1)];   // read before the rows are reused
+  if constexpr (W == 1) {
+    if (from_indices) {
+      prepare_one_from_indices<EPT>(G, s, lane, 0, t_val, oidx[0]);
+      prepare_one_from_indices<EPT>(G, s, lane, 1, s_val, oidx[NI - 1]);
+    } else {
+      // sort counters (32 EPT words, weighted only): the source CDF row, which is written after both sorts' scatters;
+      // loss only: the coordinates-by-original-index row of the sorts shares the source row
+      unsigned* counters = reinterpret_cast<unsigned*>(s_cdf);
+      float* scratch = GRAD ? gs : s_val;
+#pragma nounroll
+      for (int which = 0; which < 2; ++which) {
+        float mean;
+        int idx[EPT];
+        prepare_one<EPT, UNIFORM>(G, s, lane, which, which == 0 ? t_val : s_val, which == 0 ? t_cdf : s_cdf, scratch,
+                                  counters, idx, mean);
+        if (which == 0) {
+          mean_t = mean;
+#pragma unroll
+          for (int r = 0; r < EPT; ++r) oidx[0][r] = idx[r];
+        } else {
+          mean_s = mean;
+#pragma unroll
+          for (int r = 0; r < EPT; ++r) oidx[NI - 1][r] = idx[r];
+        }
+      }
+    }
   } else {
-    // sort counters (32 EPT words, weighted only): the source CDF row, which is written after both sorts' scatters
-    unsigned* counters = reinterpret_cast<unsigned*>(s_cdf);
-    prepare_sides<EPT, UNIFORM>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s, mean_t, counters);
-    if (!GRAD && G.idx_handoff) {                            // solve launch: leave the permutations for the gradient launch
-      unsigned short* ps = reinterpret_cast<unsigned short*>(G.cut_scratch + (long)s * n);
-      unsigned short* pt = reinterpret_cast<unsigned short*>(G.cut_scratch_t + (long)s * m);
+    if (wave < 2) {
+      const int which = 1 - wave;                            // wave 0: source, wave 1: target
+      float* dval = which == 0 ? t_val : s_val;
+      float* dcdf = which == 0 ? t_cdf : s_cdf;
+      if (from_indices) {
+        prepare_one_from_indices<EPT>(G, s, lane, which, dval, oidx[0]);
+      } else {
+        float mean;
+        // each wave's own rows serve as its sort scratch: the value row takes the coordinates by original index, the
+        // CDF row the counters; both are written with their final contents after the wave's gather
+        prepare_one<EPT, UNIFORM>(G, s, lane, which, dval, dcdf, dval, reinterpret_cast<unsigned*>(dcdf), oidx[0], mean);
+        if (lane == 0) shared[which == 0 ? 1 : 0] = mean;
+      }
+    }
+    __syncthreads();
+    mean_s = shared[0];
+    mean_t = shared[1];
+  }
+  if (!GRAD && G.idx_handoff) {                              // solve launch: leave the permutations for the gradient launch
+    unsigned short* ps = reinterpret_cast<unsigned short*>(G.cut_scratch + (long)s * n);
+    unsigned short* pt = reinterpret_cast<unsigned short*>(G.cut_scratch_t + (long)s * m);
+    if (W == 1 || wave < 2) {
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {
         const int e = lane * EPT + r;
-        if (e < n) ps[e] = (unsigned short)sidx[r];
-        if (e < m) pt[e] = (unsigned short)tidx[r];
+        if constexpr (W == 1) {
+          if (e < n) ps[e] = (unsigned short)oidx[NI - 1][r];
+          if (e < m) pt[e] = (unsigned short)oidx[0][r];
+        } else {
+          if (wave == 0 && e < n) ps[e] = (unsigned short)oidx[0][r];
+          if (wave == 1 && e < m) pt[e] = (unsigned short)oidx[0][r];
+        }
       }
     }
   }
 
   Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
   if constexpr (general_walks<EPT, UNIFORM>()) {
-    fill_walk_ext<EPT>(s_cdf, lane);
-    __builtin_amdgcn_wave_barrier();
+    if (wave == 0) fill_walk_ext<EPT>(s_cdf, lane);
+    if constexpr (W > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   }
 
   // ---- the cut: minimiser of the convex, piecewise LINEAR cost over theta in [-1, 1] -------------------
@@ -941,8 +1144,10 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
 #ifdef SHW_DBG_EVALS
   int dbg_evals = 0, dbg_bracket_at = -1;
 #endif
-  if (G.cut_given) {
-    t_mid = G.idx_handoff ? handed_cut : G.cut_scratch[(long)s * G.cut_stride];   // solved by the launch just before
+  if constexpr (GRAD) {
+    // the gradient launch never solves: launch_general always runs the loss-only kernel first and hands the cut over
+    // (cut_given = 1) -- keeping the search out of this instantiation keeps its registers for the walks
+    t_mid = G.idx_handoff ? handed_cut : G.cut_scratch[(long)s * G.cut_stride];
   } else {
     float t_lo = -1.f, t_hi = 1.f;
     t_mid = fminf(fmaxf(mean_s - mean_t, -1.f), 1.f);
@@ -950,7 +1155,7 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
     bool lo_tight = false, hi_tight = false;
     float step = G.first_step, dp_lo = 0.f, dm_hi = 0.f;
     float f_lo = 0.f, f_hi = 0.f, t_prev = 0.f, f_prev = 0.f;  // secant state (weighted clouds)
-    constexpr int kChains = EPT >= SHW_GENERAL_CHAINS ? SHW_GENERAL_CHAINS : EPT;
+    constexpr int kChains = AP >= SHW_GENERAL_CHAINS ? SHW_GENERAL_CHAINS : AP;
     int anchors[kChains] = {};                                 // first ranks of the previous evaluation (cut_slopes_walk)
     float cost_scale = 0.f;                                    // size of the cost (cut_slopes_walk)
     int last_side = 0, secant_steps = 0;
@@ -965,12 +1170,12 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
 #endif                          // <= ~25 doublings + ~25 halvings
       float dp, dm;
       if constexpr (!general_walks<EPT, UNIFORM>()) {
-        cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, dp, dm);
+        cut_slopes<EPT, PMODE, UNIFORM, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team, dp, dm);
       } else {
-        cut_slopes_walk<EPT, PMODE, kChains>(S, T, t_mid, lane, A.p, A.p_int, dp, dm, anchors, it > 0, cost_scale);
+        cut_slopes_walk<EPT, PMODE, kChains, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team, dp, dm, anchors, it > 0, cost_scale);
       }
 #ifdef SHW_DBG_TRACE
-      if (s < 4 && lane == 0) printf("slice %d it %d t %.9f dp %.4e dm %.4e lo %.9f hi %.9f\n", s, it, t_mid, dp, dm, t_lo, t_hi);
+      if (s < 4 && tid == 0) printf("slice %d it %d t %.9f dp %.4e dm %.4e lo %.9f hi %.9f\n", s, it, t_mid, dp, dm, t_lo, t_hi);
 #endif
       if (dp * dm <= 0.f) break;                               // settled on a kink / flat piece (:186-187)
       if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
@@ -992,10 +1197,10 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
       }
       if ((t_hi - t_lo) < G.min_width) {                       // :189-200
         float unused;
-        if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, dp_lo, unused);
-        if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, unused, dm_hi);
-        const float c_lo = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_lo, lane, A.p, A.p_int, nullptr, nullptr);
-        const float c_hi = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_hi, lane, A.p, A.p_int, nullptr, nullptr);
+        if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM, W>(S, T, t_lo, lane, tid, A.p, A.p_int, team, dp_lo, unused);
+        if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM, W>(S, T, t_hi, lane, tid, A.p, A.p_int, team, unused, dm_hi);
+        const float c_lo = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_lo, lane, tid, A.p, A.p_int, team);
+        const float c_hi = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_hi, lane, tid, A.p, A.p_int, team);
         float t_c = (t_lo + t_hi) * 0.5f;
         const float on_grid = G.grid > 0.f ? rintf(t_c * G.grid) / G.grid : 2.f;
         const float slack = 4e-7f;                             // a bracket end can BE the kink, seen from one side
@@ -1008,7 +1213,7 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
         }
         // never end above a bracket end: an evaluation that lands within rounding of a kink can put that kink
         // ON an end, and the candidate then sits on the wrong side of it
-        const float c_c = cut_cost<EPT, PMODE, false, UNIFORM>(S, T, t_c, lane, A.p, A.p_int, nullptr, nullptr);
+        const float c_c = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_c, lane, tid, A.p, A.p_int, team);
         t_mid = t_c;
         float best = c_c;
         if (c_lo < best) { best = c_lo; t_mid = t_lo; }
@@ -1062,47 +1267,62 @@ __global__ __launch_bounds__(64) void ssw_general_kernel(GeneralArgs G) {
         step *= 2.f;
       }
     }
-    if (G.idx_handoff) { if (lane == 0) G.cut_scratch_t[(long)s * m + (m - 1)] = t_mid; }
-    else if (G.cut_scratch) G.cut_scratch[(long)s * G.cut_stride] = t_mid;
+    // (index hand-off: the 16-bit permutation takes the first half of the target row, the cut its last word; m >= 2)
+    if (G.idx_handoff) { if (tid == 0) G.cut_scratch_t[(long)s * m + (m - 1)] = t_mid; }
+    else if (G.cut_scratch && tid == 0) G.cut_scratch[(long)s * G.cut_stride] = t_mid;
   }
 
+  float cost;
   if constexpr (GRAD) {
+    // Cost and its gradient at the cut: every atom's coefficient by its owner, once (walk_source_atoms)
+    Rotated<EPT, UNIFORM> R;
+    R.set(T, t_mid, lane);
+#ifndef SHW_DBG_WALK
+#define SHW_DBG_WALK 0      // developer timing experiments only (wrong gradients): 1 = no target walk, 2 = no walk at all
+#endif
+    float part = 0.f;
+    if (SHW_DBG_WALK < 2) part = walk_source_atoms<EPT, PMODE, UNIFORM, W>(S, R, tid, A.p, A.p_int, gs);
+    float sums[1] = {wave_sum_uniform(part, lane)};
+    if (SHW_DBG_WALK < 1) walk_target_atoms<EPT, PMODE, UNIFORM, W>(S, R, tid, A.p, A.p_int, gt, shared + 2);
+    team.sum(sums, lane);                                    // (W > 1: also the barrier that publishes gs, gt, tail)
+    cost = sums[0];
+    if constexpr (W == 1) __builtin_amdgcn_wave_barrier();
+    // un-permute through LDS (the value rows are dead now -- every wave is past its walks) and store coalesced: a
+    // direct scatter writes one 4-byte word per cache line -- 2.3 ms per launch at n=2048, m=1536
+    const float tail = shared[2];
+    float* by_index_s = s_val;
+    float* by_index_t = t_val;
+    if (W == 1 || wave == 0) {
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      scratch[r * kWave + lane] = 0.f;
-      gt[r * kWave + lane] = 0.f;
+      for (int r = 0; r < EPT; ++r) {
+        const int e = lane * EPT + r;
+        if (e < n) by_index_s[oidx[NI - 1][r]] = gs[r * kWave + lane];
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+    if (W == 1 || wave == 1) {
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) {
+        const int e = lane * EPT + r;
+        // (the first rotated atom also owns the coefficient of its copy one turn later: own part first, then the tail)
+        if (e < m) by_index_t[oidx[0][r]] = gt[r * kWave + lane] + (e == R.start ? tail : 0.f);
+      }
+    }
+    if constexpr (W > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    float* cs = A.coef_s + (long)s * n;
+    float* ct = A.coef_t + (long)s * m;
+    for (int i = tid; i < max(n, m); i += kWave * W) {
+      if (i < n) cs[i] = by_index_s[i];
+      if (i < m) ct[i] = by_index_t[i];
+    }
+  } else {
+    cost = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team);
   }
-  const float cost = cut_cost<EPT, PMODE, GRAD, UNIFORM>(S, T, t_mid, lane, A.p, A.p_int, scratch, gt);
-  if (lane == 0) {
+  if (tid == 0) {
     A.slice_cost[s] = cost;
     if (G.slice_theta) G.slice_theta[s] = t_mid;
 #ifdef SHW_DBG_EVALS                                          // developer aid: evaluations + 100 * (evaluations before the bracket)
     if (G.slice_theta && !G.cut_given) G.slice_theta[s] = (float)(dbg_evals + 100 * (dbg_bracket_at < 0 ? 0 : dbg_bracket_at));
 #endif
-  }
-  if constexpr (GRAD) {
-    __builtin_amdgcn_wave_barrier();
-    float* cs = A.coef_s + (long)s * n;
-    float* ct = A.coef_t + (long)s * m;
-    // un-permute through LDS (the value rows are dead now) and store coalesced: a direct scatter writes one
-    // 4-byte word per cache line -- 2.3 ms per launch at n=2048, m=1536, more than the whole solve
-    float* by_index_s = s_val;
-    float* by_index_t = t_val;
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int e = lane * EPT + r;
-      if (e < n) by_index_s[sidx[r]] = scratch[r * kWave + lane];
-      if (e < m) by_index_t[tidx[r]] = gt[r * kWave + lane];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int i = r * kWave + lane;
-      if (i < n) cs[i] = by_index_s[i];
-      if (i < m) ct[i] = by_index_t[i];
-    }
   }
 }
 
@@ -1445,12 +1665,14 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
     return (int)hipGetLastError();
   }
   const bool uniform = G.wu == nullptr && G.wv == nullptr;   // no weights: CDFs in closed form, no searches
+  constexpr int W = general_waves(EPT);                      // waves per slice
+  const dim3 wblock(64 * W);
 #define SHW_LAUNCH_GENERAL(PM, GR, ARGS)                                                                       \
   do {                                                                                                         \
-    const size_t lds_ = ((size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave +                          \
+    const size_t lds_ = ((size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave + kTeamFloats +            \
                          (uniform ? 0 : general_ext_floats<EPT, false>())) * sizeof(float) + SHW_DBG_EXTRA_LDS; \
-    if (uniform) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, true>), grid, block, lds_, stream, ARGS); \
-    else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, false>), grid, block, lds_, stream, ARGS);        \
+    if (uniform) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, true, W>), grid, wblock, lds_, stream, ARGS); \
+    else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, false, W>), grid, wblock, lds_, stream, ARGS);        \
   } while (0)
   if (!grad) {
     if (A.p_int == 2) SHW_LAUNCH_GENERAL(2, false, G);

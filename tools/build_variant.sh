@@ -1,12 +1,14 @@
 #!/bin/bash
-# Developer aid: A/B variant of the forward kernel (EPT=32 size class only) with extra -D flags; every other
-# object is taken from the regular build.   tools/build_variant.sh <tag> [-DFLAG ...]
+# Developer aid: build a variant of ONE translation unit with extra -D flags and link it with the other objects of the
+# current build into gpurun_variants/<name>.so (selected at run time with SHW_LIB_PATH).
+#   tools/build_variant.sh <name> <unit> [-D...]
 set -e
-TAG=$1; shift
-ROOT=$(cd $(dirname $0)/.. && pwd)
-SRC=$ROOT/sphere-homeomorphic-wasserstein-distance-for-point-cloud-registration_amd/csrc
-OUT=$ROOT/gpurun_variants; mkdir -p $OUT
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSHW_DEV_ONLY_EPT=32 "$@" -c -o $OUT/fwd_$TAG.o $SRC/shw_ssw_fwd.hip
-OBJS=$(ls $SRC/build/*.o | grep -v shw_ssw_fwd.o)
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libshw_hip_$TAG.so $OUT/fwd_$TAG.o $OBJS
-echo built $OUT/libshw_hip_$TAG.so
+NAME=$1; UNIT=$2; shift 2
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+CSRC=$(ls -d $ROOT/sphere*_amd/csrc)
+mkdir -p $ROOT/gpurun_variants/obj
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wall -Wno-unused-function "$@" \
+  -c -o $ROOT/gpurun_variants/obj/$NAME.o $CSRC/$UNIT.hip
+OTHERS=$(ls $CSRC/build/*.o | grep -v "/$UNIT.o")
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/gpurun_variants/$NAME.so $ROOT/gpurun_variants/obj/$NAME.o $OTHERS
+echo built $ROOT/gpurun_variants/$NAME.so
