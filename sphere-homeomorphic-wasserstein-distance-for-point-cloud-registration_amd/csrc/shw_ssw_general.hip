@@ -47,6 +47,7 @@ struct GeneralArgs {
   float first_step;       // first step of the bracket search around the mean-difference guess
   float min_width;        // bracket width below which the tangent intersection finishes the solve
   float grid;             // no weights: lcm(n, m) -- every kink of the cost is a multiple of 1/grid; else 0
+  int lcm, lcm_a, lcm_b;  // no weights: lcm(n, m), lcm / n, lcm / m  (n, m <= 4096: lcm < 2^24) -- the integer grid below
   // training runs as TWO launches: the solve at the loss-only kernel's occupancy (it leaves the cut of slice s in
   // cut_scratch[s * cut_stride] -- the first word of the slice's own coefficient row), then the gradient kernel
   // with cut_given = 1, which skips the solve and evaluates Cost and its gradient at that cut.
@@ -90,10 +91,43 @@ struct SliceTeam {
     }
   }
 };
+template <int W>
+__device__ __forceinline__ void team_sum2_min2(SliceTeam<W>& team, float (&sums)[2], float (&mins)[2], int lane) {
+  if constexpr (W > 1) {
+    float* slot = team.red + team.parity * (4 * W);
+    team.parity ^= 1;
+    if (lane == 0) { slot[team.wave * 4] = sums[0]; slot[team.wave * 4 + 1] = sums[1]; slot[team.wave * 4 + 2] = mins[0]; slot[team.wave * 4 + 3] = mins[1]; }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, m0 = __builtin_inff(), m1 = __builtin_inff();
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      a0 += slot[q * 4]; a1 += slot[q * 4 + 1];
+      m0 = fminf(m0, slot[q * 4 + 2]); m1 = fminf(m1, slot[q * 4 + 3]);
+    }
+    sums[0] = as_f(__builtin_amdgcn_readfirstlane(as_i(a0)));
+    sums[1] = as_f(__builtin_amdgcn_readfirstlane(as_i(a1)));
+    mins[0] = as_f(__builtin_amdgcn_readfirstlane(as_i(m0)));
+    mins[1] = as_f(__builtin_amdgcn_readfirstlane(as_i(m1)));
+  }
+}
 constexpr int kTeamFloats = 48;   // two parities of four waves' sums + the means and the tail coefficient
 
 // waves per slice by size class: the evaluations split by atoms, the two sorts take one wave each
-constexpr int general_waves(int ept) { return ept >= 64 ? 4 : (ept >= 16 ? 2 : 1); }
+#ifndef SHW_GENERAL_W32
+#define SHW_GENERAL_W32 2       // waves per slice at 1025..2048 points
+#endif
+#ifndef SHW_GENERAL_UNIFORM_BINS
+#define SHW_GENERAL_UNIFORM_BINS 0   // no weights, several waves per slice: distribution sort (half a row of counters per cloud)
+#endif
+#ifndef SHW_GENERAL_MINW_UNIFORM
+#define SHW_GENERAL_MINW_UNIFORM 3   // waves per SIMD asked of the register allocator, kernels without weights
+#endif
+constexpr int general_waves(int ept) { return ept >= 64 ? 4 : (ept == 32 ? SHW_GENERAL_W32 : (ept >= 16 ? 2 : 1)); }
+// no weights: the two value rows are all the LDS the solve needs; with W > 1 each sorting wave gets half a row of counters
+template <int EPT, bool UNIFORM, int W>
+constexpr bool general_uniform_bins() { return UNIFORM && W > 1 && EPT >= 8 && SHW_GENERAL_UNIFORM_BINS != 0; }
+template <int EPT, bool UNIFORM, int W>
+constexpr int general_counter_floats() { return general_uniform_bins<EPT, UNIFORM, W>() ? EPT * kWave : 0; }
 
 // one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout.
 // UNIFORM (no weights given, the reference's default 1/count): the CDF is (i+1)/count -- no array -- and every
@@ -921,11 +955,253 @@ __device__ __forceinline__ void sorted_cdf(float (&w)[EPT], int lane) {
   for (int r = 0; r < EPT; ++r) w[r] += offset;
 }
 
+// ---------------------------------------------------------------------------------------------
+// No weights, n != m (round 3): the solve on the INTEGER grid of lcm(n, m).
+//
+// With masses 1/n and 1/m every CDF level is a multiple of 1/G, G = lcm(n, m) = a n = b m.  Cut the unit of mass into G
+// cells: cell q belongs to source atom q / a, and -- after moving mass k / G around the circle -- to the extended target
+// atom (q + k) / b (floor division; vx(t) = v[t mod m] + floor(t / m)).  The reference's Cost (:68-113) at theta = k / G is
+//     c(k) = (1/G) sum_q | u[q / a] - vx((q + k) / b) |^p ,
+// it is linear between grid points (both quantile functions are step functions whose steps sit on the grid), so the
+// bisection of binary_search_circle (:117-207) converges to  min_k c(k),  a convex sequence -- the same statement as row
+// A8 of SURVEY 8a, which is its special case a = b = 1.  Everything here is exact integer index arithmetic: no CDF
+// arrays, no searches, no rounding questions about coinciding levels (round 2 evaluated the same thing with closed-form
+// float ranks: ~100 VALU per atom and evaluation, a divergent tie path for every third atom when n and m share a factor).
+//   * slope:  c(k+1) - c(k) = (1/G) sum over the m cells q = t b - k - 1 whose target atom changes, of
+//             |u[q/a] - vx(t)|^p - |u[q/a] - vx(t-1)|^p   (the reference's dCost, :59-63).  One pass gives the forward
+//             difference dp at k, the backward difference dm (= dp at k - 1) and how far k can move either way before
+//             any term's source atom changes (the distance to the next kink of the sequence).
+//   * search: secant / Illinois on the slope from k0 = round(G (mean u - mean v)) (exact for p = 2 and evenly spread
+//             targets), every evaluation moving the bracket at least to the next kink; ends when dm <= 0 <= dp.
+//   * cost and gradient at k*: every source atom walks the <= a/b + 2 target atoms that share cells with it (and every
+//             target atom its sources): each coefficient is accumulated by its owner and written once.
+// ---------------------------------------------------------------------------------------------
+// q = floor(x / d), r = x - q d for 0 <= x < 2^24, 1 <= d, quotient < 2^13 (indices of atoms): the fp32 quotient is
+// within one of the answer (x is exact in fp32, the quotient's error is < 2^13 * 2^-22), one correction each way
+__device__ __forceinline__ void div_small(int x, int d, float inv_d, int& q, int& r) {
+  q = (int)((float)x * inv_d);
+  r = x - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
+// k = q d + r with 0 <= r < d for |k| < 2^24 (floor division)
+__device__ __forceinline__ void floor_divmod(int k, int d, float inv_d, int& q, int& r) {
+  int qa, ra;
+  div_small(k < 0 ? -k : k, d, inv_d, qa, ra);
+  q = k < 0 ? -qa - (ra > 0 ? 1 : 0) : qa;
+  r = (k < 0 && ra > 0) ? d - ra : ra;
+}
+
+__device__ __forceinline__ int floor_div_m(int x, int m) {          // x in [-m, 2m)
+  return x < 0 ? -1 : (x >= m ? 1 : 0);
+}
+
+struct Grid {
+  int n, m, G, a, b;
+  float inv_a, inv_b;
+};
+
+
+// forward / backward differences of G c(k) at k and the distances to the neighbouring kinks; uniform over the slice
+template <int EPT, int PMODE, int W>
+__device__ void grid_slopes(const float* s_val, const float* t_val, const Grid& gr, int k, int lane, int tid, float p, int p_int,
+                            SliceTeam<W>& team, float& dm, float& dp, int& gap_left, int& gap_right) {
+  constexpr int AP = EPT / W;
+  const int a = gr.a, b = gr.b, n = gr.n, m = gr.m;
+  int kb, krem;                                                    // k = kb b + krem, 0 <= krem < b
+  floor_divmod(k, b, gr.inv_b, kb, krem);
+  const int s1 = krem == 0 ? 1 : 0;                                // dp's cells sit one target atom further when b | k
+  const int t_base = krem == 0 ? kb : kb + 1;                      // ceil(k / b)
+  const int j0 = tid * AP;
+  // atom j: t = t_base + j;  dm's cell q1 = t b - k,  dp's cell q2 = (t + s1) b - k - 1;  0 <= q < G for j < m
+  const int q1 = min((t_base + j0) * b - k, gr.G - 1);             // (threads past the last atom: clamped, masked below)
+  int i1, r1, i2, r2, bh, bl;
+  div_small(q1, a, gr.inv_a, i1, r1);
+  div_small(max(q1 + s1 * b - 1, 0), a, gr.inv_a, i2, r2);
+  div_small(b, a, gr.inv_a, bh, bl);
+  float vm = target_unrolled<EPT>(t_val, min(t_base + j0 - 1, 3 * m - 1), m);
+  float v0 = target_unrolled<EPT>(t_val, min(t_base + j0, 3 * m - 1), m);
+  float sm = 0.f, sp = 0.f;
+  int gl = 0x7fffffff, grt = 0x7fffffff;
+#pragma unroll 4
+  for (int r = 0; r < AP; ++r) {
+    const bool live = (j0 + r) < m;
+    const float vp = target_unrolled<EPT>(t_val, min(t_base + j0 + r + 1, 3 * m - 1), m);
+    const float um = s_val[lds_slot<EPT>(min(i1, n - 1))];
+    const float up = s_val[lds_slot<EPT>(min(i2, n - 1))];
+    const float hi = s1 ? vp : v0, lo = s1 ? v0 : vm;
+    const float tm = powp<PMODE>(um - v0, p, p_int) - powp<PMODE>(um - vm, p, p_int);
+    const float tp = powp<PMODE>(up - hi, p, p_int) - powp<PMODE>(up - lo, p, p_int);
+    sm += live ? tm : 0.f;
+    sp += live ? tp : 0.f;
+    gl = live ? min(gl, a - r1) : gl;
+    grt = live ? min(grt, r2 + 1) : grt;
+    vm = v0; v0 = vp;
+    r1 += bl; i1 += bh;
+    if (r1 >= a) { r1 -= a; ++i1; }
+    r2 += bl; i2 += bh;
+    if (r2 >= a) { r2 -= a; ++i2; }
+  }
+  float sums[2] = {wave_sum_uniform(sm, lane), wave_sum_uniform(sp, lane)};
+  // (distances are <= max(a, b) <= 4096: exact in fp32)
+  float mins[2] = {-wave_max(-(float)min(gl, 1 << 23), lane), -wave_max(-(float)min(grt, 1 << 23), lane)};
+  mins[0] = as_f(__builtin_amdgcn_readfirstlane(as_i(mins[0])));
+  mins[1] = as_f(__builtin_amdgcn_readfirstlane(as_i(mins[1])));
+  team_sum2_min2(team, sums, mins, lane);
+  dm = sums[0];
+  dp = sums[1];
+  gap_left = (int)mins[0];
+  gap_right = (int)mins[1];
+}
+
+// minimiser k* of the convex sequence c(k), |k| <= G (theta in [-1, 1], :174-177); uniform over the slice
+template <int EPT, int PMODE, int W>
+__device__ int grid_solve(const float* s_val, const float* t_val, const Grid& gr, float mean_s, float mean_t, int lane, int tid,
+                          float p, int p_int, SliceTeam<W>& team, int& evals) {
+  const float Gf = (float)gr.G;
+  int lo = -gr.G, hi = gr.G;
+  float guess = rintf((mean_s - mean_t) * Gf);
+  if (!(guess >= (float)lo)) guess = (float)lo;                     // (also non-finite input)
+  if (!(guess <= (float)hi)) guess = (float)hi;
+  int k = __builtin_amdgcn_readfirstlane((int)guess);
+  int k_neg = 0, k_pos = 0, k_prev = 0, last_side = 0, secant_steps = 0;
+  float f_neg = 0.f, f_pos = 0.f, f_prev = 0.f, step = 1.f;
+  bool have_neg = false, have_pos = false, have_prev = false;
+  evals = 0;
+  for (int it = 0; it < 96; ++it) {
+    float dm, dp;
+    int gl, grt;
+    grid_slopes<EPT, PMODE, W>(s_val, t_val, gr, k, lane, tid, p, p_int, team, dm, dp, gl, grt);
+    ++evals;
+    const bool right = (dp < 0.f) && (k < hi);
+    const bool left = !right && (dm > 0.f) && (k > lo);
+    if (!right && !left) break;                                    // dm <= 0 <= dp: k is a minimiser (:186-187)
+    const float f = right ? dp : dm;
+    if (right) {
+      lo = min(k + max(grt, 1), hi);                               // the slope cannot change before the next kink
+      k_neg = k; f_neg = dp; have_neg = true;
+      if (last_side > 0 && have_pos) f_pos *= 0.5f;                // Illinois: the end that stays put loses weight
+      last_side = 1;
+    } else {
+      hi = max(k - max(gl, 1), lo);
+      k_pos = k; f_pos = dm; have_pos = true;
+      if (last_side < 0 && have_neg) f_neg *= 0.5f;
+      last_side = -1;
+    }
+    if (lo >= hi) { k = lo; break; }                               // one candidate left: the minimiser
+    float next;
+    if (have_neg && have_pos) {
+      const float w = (float)(k_pos - k_neg);
+      next = (float)k_neg + rintf(w * (-f_neg) / (f_pos - f_neg));
+      if (!(next >= (float)lo && next <= (float)hi) || ++secant_steps > 24) next = (float)(lo + ((hi - lo) >> 1));
+    } else {
+      // p = 2: G c is ~quadratic in theta = k / G with curvature ~2 for clouds spread around the circle
+      if (PMODE == 2 && !have_prev) step = fmaxf(step, 0.5f * fabsf(f) * Gf);
+      next = (float)k + (right ? step : -step);
+      if (have_prev && (f - f_prev) * (float)(k - k_prev) > 0.f) {
+        const float root = (float)k - f * (float)(k - k_prev) / (f - f_prev);
+        const float over = (float)k + 1.25f * (root - (float)k);
+        next = right ? fmaxf(next, over) : fminf(next, over);
+      }
+      step *= 2.f;
+    }
+    next = fminf(fmaxf(rintf(next), (float)lo), (float)hi);
+    k_prev = k; f_prev = f; have_prev = true;
+    k = __builtin_amdgcn_readfirstlane((int)next);
+  }
+  return k;
+}
+
+// G * Cost at the shift k, the thread's share (sum over its source atoms); GRAD: G * d Cost / d (sorted source atom) into gs
+template <int EPT, int PMODE, bool GRAD, int W>
+__device__ float grid_cost_source(const float* s_val, const float* t_val, const Grid& gr, int k, int tid, float p, int p_int,
+                                  float* gs) {
+  constexpr int AP = EPT / W;
+  const int a = gr.a, b = gr.b, n = gr.n, m = gr.m;
+  const int trips = (a + b - 2) / b + 1;                           // a source atom's a cells meet at most this many targets
+  float cost = 0.f;
+  int e = tid * AP;
+  // cells [e a, (e+1) a): the first one belongs to target t = floor((e a + k) / b), rb cells into it
+  int kb, krem, t, rb, ah, al;
+  floor_divmod(k, b, gr.inv_b, kb, krem);
+  div_small(min(e, n - 1) * a + krem, b, gr.inv_b, t, rb);         // (< G + b <= 2^24)
+  t += kb;
+  div_small(a, b, gr.inv_b, ah, al);
+#pragma nounroll
+  for (int r = 0; r < AP; ++r, ++e) {
+    const bool live = e < n;
+    const float u = s_val[lds_slot<EPT>(min(e, n - 1))];
+    float acc = 0.f, part = 0.f;
+    int left = a, tt = t, off = rb;
+    for (int s = 0; s < trips; ++s) {
+      const int len = min(left, b - off);                          // cells shared with target tt (0 once the atom is used up)
+      const float d = u - target_unrolled<EPT>(t_val, min(tt, 3 * m - 1), m);
+      part = fmaf((float)len, powp<PMODE>(d, p, p_int), part);
+      if constexpr (GRAD) acc = fmaf((float)len, dpow_abs<PMODE>(d, p, p_int), acc);
+      left -= len;
+      off = 0;
+      ++tt;
+    }
+    cost += live ? part : 0.f;
+    if constexpr (GRAD) {
+      if (live) gs[lds_slot<EPT>(e)] = acc;
+    }
+    rb += al; t += ah;
+    if (rb >= b) { rb -= b; ++t; }
+  }
+  return cost;
+}
+
+// GRAD: G * d Cost / d (sorted target atom) into gt.  Thread tid owns the extended target atoms T0 + [tid AP, (tid+1) AP),
+// T0 = floor(k / b); when b does not divide k the first of them holds only part of its cells and the rest sit one turn
+// later at T0 + m -- the owner of the last atom walks that instance too and hands its sum over in *tail (it belongs to
+// sorted atom T0 mod m, which adds it to its own part: a fixed order).
+template <int EPT, int PMODE, int W>
+__device__ void grid_grad_target(const float* s_val, const float* t_val, const Grid& gr, int k, int tid, float p, int p_int,
+                                 float* gt, float* tail) {
+  constexpr int AP = EPT / W;
+  const int a = gr.a, b = gr.b, n = gr.n, m = gr.m, G = gr.G;
+  const int trips = (a + b - 2) / a + 1;                           // a target atom's b cells meet at most this many sources
+  int T0, krem;
+  floor_divmod(k, b, gr.inv_b, T0, krem);                          // T0 = floor(k / b)
+  const int rho0 = tid * AP;
+  const bool owns_tail = rho0 < m && rho0 + AP >= m;               // owner of the last extended atom
+  const int rho_end = owns_tail ? m + 1 : min(rho0 + AP, m);
+  int j = T0 + rho0;                                               // sorted atom of instance rho: (T0 + rho) mod m
+  j += j < 0 ? m : 0;
+  j -= j >= m ? m : 0;
+  j -= j >= m ? m : 0;
+#pragma nounroll
+  for (int rho = rho0; rho < rho_end; ++rho) {
+    const int t = T0 + rho;
+    const float v = target_unrolled<EPT>(t_val, t, m);             // t in [-m, 2m]
+    const int q_lo = max(t * b - k, 0);
+    const int q_hi = min((t + 1) * b - k, G);                      // (rho = m with b | k: no cells, the sum is 0)
+    int i, ra;
+    div_small(min(q_lo, G - 1), a, gr.inv_a, i, ra);
+    int left = max(q_hi - q_lo, 0);
+    float acc = 0.f;
+    for (int s = 0; s < trips; ++s) {
+      const int len = min(left, a - ra);
+      const float d = s_val[lds_slot<EPT>(min(i, n - 1))] - v;
+      acc = fmaf((float)len, dpow_abs<PMODE>(d, p, p_int), acc);
+      left -= len;
+      ra = 0;
+      ++i;
+    }
+    if (rho < m) gt[lds_slot<EPT>(j)] = -acc;
+    else *tail = -acc;
+    ++j;
+    j -= j >= m ? m : 0;
+  }
+}
+
 // project, sort (with indices), gather weights and build the CDF of ONE cloud of slice s (which = 0: target, 1: source);
 // leaves the sorted values / CDF in LDS (dval, dcdf) and the sorted->original index map in registers.  `scratch` is a row
 // for the coordinates by original index (it may be dval itself: the gather out of it is complete before the sorted values
 // are written, LDS operations of a wave execute in order), `counters` 32 EPT words for the distribution sort.
-template <int EPT, bool UNIFORM = false>
+template <int EPT, bool UNIFORM = false, bool BINS = (EPT >= 8 && !UNIFORM)>
 __device__ __forceinline__ void prepare_one(const GeneralArgs& G, int s, int lane, int which, float* dval, float* dcdf,
                                             float* scratch, unsigned* counters, int (&idx)[EPT], float& mean_out) {
   const SswArgs& A = G.base;
@@ -944,7 +1220,7 @@ __device__ __forceinline__ void prepare_one(const GeneralArgs& G, int s, int lan
   // row).  Without weights the one-wave kernel ran two waves per SIMD on 248 registers and the distribution sort's extra
   // live words spilled (measured in round 2: 2.1 -> 3.3 ms at n = 2048, m = 1536): it keeps the network.
   float part;
-  if constexpr (EPT >= 8 && !UNIFORM) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
+  if constexpr (BINS) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
   else part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
   float mean = 0.f;                                        // mass-weighted mean coordinate (first guess of the cut)
   if constexpr (UNIFORM) {
@@ -1027,7 +1303,7 @@ __device__ __forceinline__ void prepare_one_from_indices(const GeneralArgs& G, i
 }
 
 template <int EPT, int PMODE, bool GRAD, bool UNIFORM, int W>
-__global__ __launch_bounds__(64 * W, W > 1 ? 2 : 1) void ssw_general_kernel(GeneralArgs G) {
+__global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM : 2) : 1) void ssw_general_kernel(GeneralArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave;
   constexpr int AP = EPT / W;                                // sorted atoms per thread in the evaluations
@@ -1046,7 +1322,9 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 2 : 1) void ssw_general_kernel(Gene
   float* grad_rows = lds + (UNIFORM ? 2 : 4) * ROW + EXT;    // GRAD only: two rows of coefficients by sorted position
   float* gs = grad_rows;
   float* gt = grad_rows + ROW;
-  float* team_mem = lds + ((UNIFORM ? 2 : 4) + (GRAD ? 2 : 0)) * ROW + EXT;
+  constexpr int CNT = general_counter_floats<EPT, UNIFORM, W>();   // no weights, W > 1: counters of the two distribution sorts
+  float* team_mem = lds + ((UNIFORM ? 2 : 4) + (GRAD ? 2 : 0)) * ROW + EXT + CNT;
+  unsigned* own_counters = reinterpret_cast<unsigned*>(team_mem - CNT + (wave & 1) * (CNT / 2));
   SliceTeam<W> team{team_mem, wave, 0};
   float* shared = team_mem + 8 * W;                          // [0], [1]: the two mean coordinates; [2]: the tail coefficient
 
@@ -1098,7 +1376,9 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 2 : 1) void ssw_general_kernel(Gene
         float mean;
         // each wave's own rows serve as its sort scratch: the value row takes the coordinates by original index, the
         // CDF row the counters; both are written with their final contents after the wave's gather
-        prepare_one<EPT, UNIFORM>(G, s, lane, which, dval, dcdf, dval, reinterpret_cast<unsigned*>(dcdf), oidx[0], mean);
+        constexpr bool UBINS = general_uniform_bins<EPT, UNIFORM, W>();
+        prepare_one<EPT, UNIFORM, UBINS || (EPT >= 8 && !UNIFORM)>(
+            G, s, lane, which, dval, dcdf, dval, UBINS ? own_counters : reinterpret_cast<unsigned*>(dcdf), oidx[0], mean);
         if (lane == 0) shared[which == 0 ? 1 : 0] = mean;
       }
     }
@@ -1124,6 +1404,67 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 2 : 1) void ssw_general_kernel(Gene
     }
   }
 
+  if constexpr (UNIFORM) {
+    // ---- no weights: the solve on the integer grid of lcm(n, m) (grid_* above) ------------------------------------
+    const Grid gr{n, m, G.lcm, G.lcm_a, G.lcm_b, 1.f / (float)G.lcm_a, 1.f / (float)G.lcm_b};
+    const float inv_G = 1.f / (float)gr.G;
+    int k;
+    if constexpr (GRAD) {
+      // (the gradient launch never solves: launch_general runs the loss-only kernel first, which hands the shift over as
+      //  the bits of an int in the slice's own coefficient row)
+      k = __float_as_int(G.idx_handoff ? handed_cut : G.cut_scratch[(long)s * G.cut_stride]);
+    } else {
+      int evals;
+      k = grid_solve<EPT, PMODE, W>(s_val, t_val, gr, mean_s, mean_t, lane, tid, A.p, A.p_int, team, evals);
+      // (index hand-off: the 16-bit permutation takes the first half of the target row, the shift its last word; m >= 2)
+      if (G.idx_handoff) { if (tid == 0) G.cut_scratch_t[(long)s * m + (m - 1)] = __int_as_float(k); }
+      else if (G.cut_scratch && tid == 0) G.cut_scratch[(long)s * G.cut_stride] = __int_as_float(k);
+#ifdef SHW_DBG_EVALS
+      if (G.slice_theta && tid == 0) G.slice_theta[s] = (float)evals;
+#endif
+    }
+    float sums[1] = {wave_sum_uniform(grid_cost_source<EPT, PMODE, GRAD, W>(s_val, t_val, gr, k, tid, A.p, A.p_int, gs), lane)};
+    if constexpr (GRAD) grid_grad_target<EPT, PMODE, W>(s_val, t_val, gr, k, tid, A.p, A.p_int, gt, shared + 2);
+    team.sum(sums, lane);                                    // (W > 1: also the barrier that publishes gs, gt, tail)
+    if (tid == 0) {
+      A.slice_cost[s] = sums[0] * inv_G;
+#ifndef SHW_DBG_EVALS
+      if (G.slice_theta) G.slice_theta[s] = (float)k * inv_G;
+#endif
+    }
+    if constexpr (GRAD) {
+      if constexpr (W == 1) __builtin_amdgcn_wave_barrier();
+      // un-permute through LDS (the value rows are dead now -- every wave is past its loops) and store coalesced
+      const float tail = shared[2];
+      int jstart, unused;
+      floor_divmod(k, gr.b, gr.inv_b, jstart, unused);        // floor(k / b): its atom owns the tail
+      jstart -= floor_div_m(jstart, m) * m;
+      float* by_index_s = s_val;
+      float* by_index_t = t_val;
+      if (W == 1 || wave == 0) {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          const int e = lane * EPT + r;
+          if (e < n) by_index_s[oidx[NI - 1][r]] = gs[r * kWave + lane] * inv_G;
+        }
+      }
+      if (W == 1 || wave == 1) {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          const int e = lane * EPT + r;
+          // (the atom of the first extended instance also owns the cells one turn later: own part first, then the tail)
+          if (e < m) by_index_t[oidx[0][r]] = (gt[r * kWave + lane] + (e == jstart ? tail : 0.f)) * inv_G;
+        }
+      }
+      if constexpr (W > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+      float* cs = A.coef_s + (long)s * n;
+      float* ct = A.coef_t + (long)s * m;
+      for (int i = tid; i < max(n, m); i += kWave * W) {
+        if (i < n) cs[i] = by_index_s[i];
+        if (i < m) ct[i] = by_index_t[i];
+      }
+    }
+  } else {
   Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
   if constexpr (general_walks<EPT, UNIFORM>()) {
     if (wave == 0) fill_walk_ext<EPT>(s_cdf, lane);
@@ -1324,6 +1665,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? 2 : 1) void ssw_general_kernel(Gene
     if (G.slice_theta && !G.cut_given) G.slice_theta[s] = (float)(dbg_evals + 100 * (dbg_bracket_at < 0 ? 0 : dbg_bracket_at));
 #endif
   }
+  }   // weighted clouds
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1670,7 +2012,8 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
 #define SHW_LAUNCH_GENERAL(PM, GR, ARGS)                                                                       \
   do {                                                                                                         \
     const size_t lds_ = ((size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave + kTeamFloats +            \
-                         (uniform ? 0 : general_ext_floats<EPT, false>())) * sizeof(float) + SHW_DBG_EXTRA_LDS; \
+                         (uniform ? general_counter_floats<EPT, true, W>() : general_ext_floats<EPT, false>())) *  \
+                        sizeof(float) + SHW_DBG_EXTRA_LDS;                                                      \
     if (uniform) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, true, W>), grid, wblock, lds_, stream, ARGS); \
     else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, false, W>), grid, wblock, lds_, stream, ARGS);        \
   } while (0)
@@ -1708,9 +2051,12 @@ static int gcd_general(int a, int b) {
 
 int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                      float* slice_theta, hipStream_t stream) {
-  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0.f, nullptr, nullptr, 0, 0, 0};
+  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0.f, 0, 0, 0, nullptr, nullptr, 0, 0, 0};
   if (wu == nullptr && wv == nullptr) {                      // kinks sit on the grid of 1 / lcm(n, m)
     const double lcm = (double)A.n / (double)gcd_general(A.n, A.m) * (double)A.m;
+    G.lcm = (int)lcm;                                        // n, m <= 4096: < 2^24 -- the integer grid of the solve
+    G.lcm_a = G.lcm / A.n;
+    G.lcm_b = G.lcm / A.m;
     G.grid = lcm <= 4.0e6 ? (float)lcm : 0.f;                // (finer than 2.5e-7: leave it to the tangent step)
     G.first_step = (float)(1.0 / lcm);
     G.min_width = (float)(0.5 / lcm);
