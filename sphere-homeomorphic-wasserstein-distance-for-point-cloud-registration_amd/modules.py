@@ -148,6 +148,62 @@ class GraphedAscent:
                 observer(float(value.sum()))
 
 
+class GraphedStep:
+    """hipGraph capture of a WHOLE optimisation step -- zero_grad, loss, backward, optimizer step -- for callers whose step is
+    launch-bound.  The notebooks' gradient flow (Wasserstein_flow_problem/Flow_cube.ipynb:1372-1395: one 1200-point pair,
+    100 slices, `loss = sliced_wasserstein_sphere(evolving, target, 100, device, p=2); loss.backward(); optimizer.step()`) is
+    ~15 launches of 2-20 us each: 58 us of GPU work inside 0.29 ms of launch and Python overhead per step (round 3,
+    profiles/r03_notebook_*).  Replayed as one graph the step costs what the GPU work costs.
+
+        step = shw.GraphedStep(lambda: shw.sliced_wasserstein_sphere(evolving, target, 100, device, p=2), optimizer)
+        for i in range(400):
+            loss = step()            # a static tensor that holds the loss of the step just replayed
+
+    Requirements of graph capture: the tensors the closure reads and the optimizer's parameters keep their addresses
+    (update them in place), and the optimizer's step is capturable (`torch.optim.Adam([...], capturable=True)`; add
+    `fused=True` for one kernel instead of eight).  Directions drawn inside the loss stay random across replays: torch
+    registers the device generator with the graph.  The first `warmup` calls run eagerly on a side stream (they are real
+    steps), the next one captures, every later call is a replay of the same kernels on the same buffers -- bit-identical
+    to the eager loop (tests/test_r3_gpu.py)."""
+
+    def __init__(self, loss_fn, optimizer, warmup=3):
+        self.loss_fn, self.optimizer, self.warmup = loss_fn, optimizer, warmup
+        self._calls = 0
+        self._graph = None
+        self._loss = None
+        for group in optimizer.param_groups:
+            if not group.get("capturable", False):
+                raise RuntimeError("the optimizer must be created with capturable=True to be replayed in a hipGraph")
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn()
+        loss.sum().backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self):
+        if self._graph is not None:
+            self._graph.replay()
+            return self._loss
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        device = params[0].device
+        if self._calls < self.warmup:
+            self._calls += 1
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                loss = self._step()
+            torch.cuda.current_stream(device).wait_stream(side)
+            return loss
+        self._graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self._graph):
+            self._loss = self._step()
+        self._graph.replay()                # capture records, it does not execute: this is the step of this call
+        return self._loss
+
+
 class max_spherical_wassersten_distance_fast(max_spherical_wassersten_distance):
     """phi-max wrapper, batched SSW (_fast.py:346-380).  `graph=True`: the inner ascent iterations are captured once
     per input shape and replayed (GraphedAscent); the returned value and maps are computed eagerly as in the

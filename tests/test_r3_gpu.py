@@ -238,3 +238,44 @@ def test_general_path_gradients_are_bit_identical_from_run_to_run(shw, n, m, p, 
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
     assert torch.isfinite(runs[0][1]).all() and torch.isfinite(runs[0][2]).all()
+
+
+# ------------------------------------------------------------------------------------------- the notebook step as a hipGraph
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_step_replays_the_eager_flow_bit_for_bit(shw, golden, fused):
+    """the notebooks' step (zero_grad, loss, backward, Adam step; Flow_cube.ipynb:1372-1395) captured
+    once and replayed (shw.GraphedStep) must do what the eager loop does: same kernels, same buffers, same bits.  Fixed
+    directions so that both loops see the same slices; 3 eager warm-up steps + capture + 6 replays against 10 eager steps."""
+    g = golden("g10_notebook_flow.npz")
+    target, U = dev(g["target"]), dev(g["U"])
+
+    def flow(graphed):
+        evolving = dev(g["source"]).requires_grad_(True)
+        opt = torch.optim.Adam([evolving], lr=0.01, capturable=True, fused=fused)
+
+        def loss_fn():
+            return shw.sliced_cost(evolving, target, U, p=2)
+        losses = []
+        if graphed:
+            step = shw.GraphedStep(loss_fn, opt, warmup=3)
+            for _ in range(10):
+                losses.append(step().clone())
+        else:
+            for _ in range(10):
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn()
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+        return torch.stack(losses), evolving.detach().clone()
+
+    le, xe = flow(False)
+    lg, xg = flow(True)
+    assert torch.equal(le, lg) and torch.equal(xe, xg)
+    assert le[-1] < le[0]                                   # and it is a descent
+
+
+def test_graphed_step_refuses_an_optimizer_that_cannot_be_captured(shw):
+    x = torch.zeros(8, 3, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="capturable"):
+        shw.GraphedStep(lambda: x.sum(), torch.optim.Adam([x], lr=0.1))
