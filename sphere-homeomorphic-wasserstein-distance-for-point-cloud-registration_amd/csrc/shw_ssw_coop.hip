@@ -166,4 +166,18 @@ int dispatch_forward_coop(SswArgs& A, hipStream_t stream) {
   }
 }
 
+// Small grids (round 3; see dispatch_forward_grad_small_grid): fewer (pair, slice) problems than SIMDs -- 8 keys per lane,
+// W = padded / 512 waves per slice
+int dispatch_forward_small_grid(SswArgs& A, hipStream_t stream) {
+  const int padded = next_pow2(A.n > A.m ? A.n : A.m);
+  switch (padded / 512) {
+#ifndef SHW_DEV_ONLY_EPT
+    case 1: return launch_forward_coop<8, 1>(A, stream);
+    case 2: return launch_forward_coop<8, 2>(A, stream);
+    case 4: return launch_forward_coop<8, 4>(A, stream);
+#endif
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
 }  // namespace shw

@@ -309,11 +309,25 @@ static int forward_family() {
   return fam;
 }
 
+int dispatch_forward_small_grid(SswArgs& A, hipStream_t stream);   // shw_ssw_coop.hip
+
+// launches with at most this many (pair, slice) problems take the small-grid kernels (SHW_SMALL_GRID overrides; 0 = never)
+static long small_grid_slices() {
+  static const long v = [] {
+    const char* e = getenv("SHW_SMALL_GRID");
+    return e ? atol(e) : 1024L;
+  }();
+  return v;
+}
+
 int dispatch_forward(SswArgs& A, hipStream_t stream) {
 #ifndef SHW_NO_COOP
   {
     const int padded = next_pow2(A.n > A.m ? A.n : A.m);
     const int fam = forward_family();
+    // fewer problems than SIMDs: latency-bound, W waves per slice of 8 keys per lane
+    if (fam == 0 && padded >= 512 && padded <= 2048 && (long)A.pairs * A.slices <= small_grid_slices())
+      return dispatch_forward_small_grid(A, stream);
     if ((fam == 0 && padded > 2048) || (fam == 2 && padded >= 2048)) return dispatch_forward_coop(A, stream);
     if (padded >= 512 && padded <= 2048 && fam != 4 && fam != 1) {
       const bool headline = (A.n == 2048 && A.m == 2048);

@@ -253,9 +253,23 @@ static bool grad_one_wave_forced() {
   return forced;
 }
 
+int dispatch_forward_grad_small_grid(SswArgs& A, hipStream_t stream);   // shw_ssw_grad_coop.hip
+
+// launches with at most this many (pair, slice) problems take the small-grid kernels (SHW_SMALL_GRID overrides; 0 = never)
+static long small_grid_slices() {
+  static const long v = [] {
+    const char* e = getenv("SHW_SMALL_GRID");
+    return e ? atol(e) : 1024L;
+  }();
+  return v;
+}
+
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream) {
   {
     const int ept = ept_for(A.n, A.m);
+    // fewer problems than SIMDs: latency-bound, W waves per slice (shw_ssw_grad_coop.hip, small grids)
+    if (ept >= 8 && ept <= 32 && (long)A.pairs * A.slices <= small_grid_slices() && !grad_one_wave_forced())
+      return dispatch_forward_grad_small_grid(A, stream);
     if (ept >= 8 && ept <= 32 && !grad_one_wave_forced()) return dispatch_forward_grad2(A, stream);   // shw_ssw_grad2.hip
     if ((ept == 64 || ept == 128) && !grad_one_wave_forced()) return dispatch_forward_grad_coop(A, stream);   // shw_ssw_grad_coop.hip
   }

@@ -235,4 +235,22 @@ int dispatch_forward_grad_coop(SswArgs& A, hipStream_t stream) {
   }
 }
 
+// Small grids (round 3): when a launch has fewer (pair, slice) problems than the chip has SIMDs -- the notebooks' gradient
+// flow is ONE pair x 100 slices (Flow_cube.ipynb:1381) -- a slice is latency, not throughput: 8 atoms per lane and
+// W = padded / 512 waves per slice (4 at 1025..2048 points) cut the dependent chain of the sort and the solve and put
+// 400 waves on the chip instead of 200.  (For full grids the same form is slower: wave scans, barriers and the seam sort
+// are paid W times -- profiles/r02_ab_coop_keys_per_lane.txt.)
+int dispatch_forward_grad_small_grid(SswArgs& A, hipStream_t stream) {
+  if (A.n != A.m) return (int)hipErrorInvalidValue;
+  const int padded = next_pow2(A.n);
+  switch (padded / 512) {
+#ifndef SHW_DEV_ONLY_EPT
+    case 1: return launch_forward_grad_coop<8, 1>(A, stream);
+    case 2: return launch_forward_grad_coop<8, 2>(A, stream);
+    case 4: return launch_forward_grad_coop<8, 4>(A, stream);
+#endif
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
 }  // namespace shw

@@ -8,7 +8,10 @@
   the size classes between the powers of two (1200, 1280, 1500, 2000 ...) for loss and gradients.
 Tolerances are stated at each assertion.
 """
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -279,3 +282,57 @@ def test_graphed_step_refuses_an_optimizer_that_cannot_be_captured(shw):
     x = torch.zeros(8, 3, device="cuda", requires_grad=True)
     with pytest.raises(RuntimeError, match="capturable"):
         shw.GraphedStep(lambda: x.sum(), torch.optim.Adam([x], lr=0.1))
+
+
+# ------------------------------------------------------------------------------------------- small grids: W waves per slice
+_SMALL_GRID_SCRIPT = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import shw_amd
+out = {}
+for (n, p, kind) in ((600, 2, "sphere"), (1000, 2, "sphere"), (1200, 2, "cube"), (1500, 3, "sphere"), (2000, 2, "sphere"),
+                     (2048, 2, "sphere"), (1024, 2.5, "sphere"), (1200, 2, "lattice"), (512, 2, "sphere")):
+    g = torch.Generator().manual_seed(7 * n + len(kind))
+    x, y = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+    if kind == "sphere":
+        x, y = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(y, dim=-1)
+    elif kind == "cube":                 # un-normalised, like the notebooks' clouds
+        x = x.clamp(-1, 1)
+    else:                                # few lattice sites: duplicate points, long runs of equal coordinates
+        x, y = torch.round(x * 4) / 4 + 0.01, torch.round(y * 4) / 4 + 0.01
+    U = torch.linalg.qr(torch.randn(10, 3, 2, generator=g))[0]
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, shift = shw_amd.ssw_pair_losses(xs[None], ys[None], U.cuda(), p=p, return_slices=True)
+    pair.sum().backward()
+    _, cost_fwd, shift_fwd = shw_amd.ssw_pair_losses(x.cuda()[None], y.cuda()[None], U.cuda(), p=p, return_slices=True)
+    out[f"{n}p{p}{kind}"] = {"cost": cost[0].tolist(), "shift": shift[0].tolist(), "cost_fwd": cost_fwd[0].tolist(),
+                            "shift_fwd": shift_fwd[0].tolist(), "gx": xs.grad.cpu().numpy().tolist(),
+                            "gy": ys.grad.cpu().numpy().tolist()}
+print(json.dumps(out))
+"""
+
+
+def test_small_grid_kernels_agree_with_the_throughput_kernels(shw):
+    """a launch with fewer (pair, slice) problems than SIMDs (the notebooks: 1 pair x 100 slices) takes
+    the cooperative kernels with 8 keys per lane and W = padded / 512 waves per slice.  SHW_SMALL_GRID=0 keeps the
+    throughput kernels (two waves per slice, 32 keys per lane) for any grid: the same seeded cases in two subprocesses must
+    give the same shifts, costs to 3e-6 and -- both sorts being stable -- the same gradients, also on un-normalised clouds
+    and on clouds of duplicate points."""
+    res = {}
+    for forced in ("0", "1024"):
+        env = dict(os.environ, SHW_SMALL_GRID=forced)
+        r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT, ROOT], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[forced] = json.loads(r.stdout.strip().split("\n")[-1])
+    for key in res["0"]:
+        a, b = res["0"][key], res["1024"][key]
+        for f in ("cost", "cost_fwd"):
+            ca, cb = np.array(a[f]), np.array(b[f])
+            assert np.all(np.abs(ca - cb) <= 3e-6 * np.abs(cb) + 1e-12), (key, f)
+        same_shift = np.array(a["shift"]) == np.array(b["shift"])
+        assert same_shift.mean() >= 0.9, key                       # (exact cost ties may pick either shift)
+        for f in ("gx", "gy"):
+            ga, gb = np.array(a[f]), np.array(b[f])
+            assert np.isfinite(gb).all()
+            if same_shift.all():
+                assert np.abs(ga - gb).max() <= 1e-6 * np.abs(ga).max() + 1e-12, (key, f)
