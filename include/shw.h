@@ -29,7 +29,8 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its only dynamic symbols */
 #define SHW_API __attribute__((visibility("default")))
 
-#define SHW_ABI_VERSION 3 /* 2: shw_ssw_backward_points takes per-pair upstream weights; 3: shw_circle_ot takes `method` */
+#define SHW_ABI_VERSION 3 /* 2: shw_ssw_backward_points takes per-pair upstream weights; 3: shw_circle_ot takes `method`,
+                             shw_sinkhorn_forward_train takes plan / cost_matrix */
 #define SHW_MAX_POINTS 8192 /* per cloud, per pair */
 
 /* ABI version of the loaded library (== SHW_ABI_VERSION of the header it was built from). */
@@ -205,12 +206,14 @@ SHW_API int shw_sinkhorn_forward(const float* x, const float* y, int pairs, int 
  * from the points (nothing dense is stored), every gradient row owned by one thread (deterministic):
  *   grad_cost (pairs) in : upstream gradient of cost[b];  grad_x (pairs, n, 3), grad_y (pairs, m, 3) out (overwritten).
  * The workspace must be passed unchanged from the forward to the backward call (same sizes, eps, max_iter, norms).
+ * plan, cost_matrix (ABI 3): optional dense (pairs, n, m) outputs P and C of the SAME solve (NULL to skip), plain values: the
+ * gradient this library computes is that of `cost`.
  */
 SHW_API size_t shw_sinkhorn_train_workspace_bytes(int pairs, int n, int m, int max_iter);
 
 SHW_API int shw_sinkhorn_forward_train(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
-                                       int norm_p, int cost_pow, float thresh, void* workspace, float* cost,
-                                       void* stream);
+                                       int norm_p, int cost_pow, float thresh, void* workspace, float* cost, float* plan,
+                                       float* cost_matrix, void* stream);
 
 SHW_API int shw_sinkhorn_backward(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
                                   int norm_p, int cost_pow, void* workspace, const float* grad_cost, float* grad_x,

@@ -52,7 +52,7 @@ _SIGNATURES = {
     "shw_sinkhorn_train_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "shw_sinkhorn_forward_train": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
-                                                  _c_f32p, ctypes.c_void_p]),
+                                                  _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "shw_sinkhorn_backward": (ctypes.c_int, [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, _c_f32p, _c_f32p,
                                              _c_f32p, ctypes.c_void_p]),

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void sinkhorn_cost_kernel(SinkArgs A, float* _
 __global__ __launch_bounds__(256) void sinkhorn_cost_traj_kernel(const float* x, const float* y, const float* tu,
                                                                  const float* tv, const int* done, int pairs, int n, int m,
                                                                  float inv_eps, int norm_p, int cost_pow,
-                                                                 float* __restrict__ partial) {
+                                                                 float* __restrict__ partial, float* __restrict__ P,
+                                                                 float* __restrict__ Cm) {
   __shared__ float4 tile[kSkTile];
   __shared__ float red[4];
   const int b = blockIdx.y;
@@ -207,7 +208,12 @@ __global__ __launch_bounds__(256) void sinkhorn_cost_traj_kernel(const float* x,
       const float4 q = tile[t];
       const float c = pair_cost<false>(rx - q.x, ry - q.y, rz - q.z, norm_p, cost_pow);
       const float p = expf(((ui - c) + q.w) * inv_eps);
-      if (i < n) acc = fmaf(p, c, acc);
+      if (i < n) {
+        acc = fmaf(p, c, acc);
+        // the dense plan and cost matrix the reference returns (sinkhorn.py:52-58), on request, from the SAME solve
+        if (P) P[((long)b * n + i) * m + base + t] = p;
+        if (Cm) Cm[((long)b * n + i) * m + base + t] = c;
+      }
     }
   }
   acc = wave_sum(acc, threadIdx.x & 63);
@@ -485,7 +491,8 @@ static void sink_train_layout(void* workspace, int pairs, int n, int m, int max_
 }
 
 int shw_sinkhorn_forward_train(const float* x, const float* y, int pairs, int n, int m, float eps, int max_iter,
-                               int norm_p, int cost_pow, float thresh, void* workspace, float* cost, void* stream) {
+                               int norm_p, int cost_pow, float thresh, void* workspace, float* cost, float* plan,
+                               float* cost_matrix, void* stream) {
   if (!x || !y || !workspace || !cost) return (int)hipErrorInvalidValue;
   if (pairs < 0 || pairs > 65535 || n < 1 || m < 1 || !(eps > 0.f) || max_iter < 0 || norm_p < 1 || cost_pow < 1)
     return (int)hipErrorInvalidValue;
@@ -517,7 +524,7 @@ int shw_sinkhorn_forward_train(const float* x, const float* y, int pairs, int n,
   }
   // the value: cost kernel on the last EXECUTED slot (device-side count)
   hipLaunchKernelGGL(shw::sinkhorn_cost_traj_kernel, grid_u, dim3(256), 0, st, x, y, tu, tv, done, pairs, n, m, 1.f / eps,
-                     norm_p, cost_pow, partial);
+                     norm_p, cost_pow, partial, plan, cost_matrix);
   hipLaunchKernelGGL(shw::sinkhorn_cost_reduce_kernel, dim3(pairs), dim3(64), 0, st, partial, (int)blocks, cost);
   return (int)hipGetLastError();
 }

@@ -7,8 +7,9 @@
 Notes on the reference cell: it draws the directions on the CPU generator and moves them to `device`
 (`torch.randn((L, dim))` then `.to(device)`), which this mirror does too; it reads a *global* `num_projections`
 instead of its own `num_projection` argument (a notebook slip) -- here the argument is used.  The notebook cannot
-be imported (its `datas` / `losses` modules are not shipped), so this baseline is pinned by the restatement in
-oracle/euclid_sw.py only: PARITY UNPINNED by reference fixtures.
+be imported (its `datas` / `losses` modules are not shipped); the cell itself is self-contained torch code and fixture
+G9 (tests/golden/g9_notebook_esw.npz, oracle/make_golden.py) holds its outputs -- values and gradients -- exec'd from
+the .ipynb JSON: the family is pinned by the reference (round 2).
 `max_sliced_wasserstein_distance` (:294-323: Adam ascent on ONE direction, then the distance along it) is mirrored
 too; the op is differentiable w.r.t. the clouds and the directions."""
 from __future__ import annotations

@@ -8,8 +8,9 @@ main_rotation.py:207-211):
 Differentiable like the reference (its forward is autograd-visible through the unrolled iterations, :35-49): when a
 cloud requires grad the iterations keep the trajectory of the duals and `backward` walks it (shw_sinkhorn_backward;
 round 2).  The dense plan P and cost matrix C the
-reference returns are produced on request (`return_plan=True`, the default, keeps the call a drop-in;
-`return_plan=False` returns (cost, None, None) and never allocates the two (B, n, m) tensors)."""
+reference returns are produced on request by the SAME solve (`return_plan=True`, the default, keeps the call a drop-in;
+`return_plan=False` returns (cost, None, None) and never allocates the two (B, n, m) tensors).  In training P and C are
+plain values marked non-differentiable (the reference's are autograd-visible): the gradient is that of the cost."""
 from __future__ import annotations
 
 import torch
@@ -22,7 +23,7 @@ class _SinkhornCosts(torch.autograd.Function):
     """(B,n,3), (B,m,3) -> (B,) costs with the gradient through the unrolled iterations."""
 
     @staticmethod
-    def forward(ctx, x, y, eps, max_iter, norm_p, cost_pow, thresh):
+    def forward(ctx, x, y, eps, max_iter, norm_p, cost_pow, thresh, return_plan):
         lib = _lib.load()
         B, n, _ = x.shape
         m = y.shape[1]
@@ -30,16 +31,23 @@ class _SinkhornCosts(torch.autograd.Function):
         xc, yc = x.contiguous(), y.contiguous()
         ws = torch.empty(lib.shw_sinkhorn_train_workspace_bytes(B, n, m, max_iter), dtype=torch.uint8, device=dev)
         cost = torch.empty(B, dtype=torch.float32, device=dev)
+        # the dense outputs of the reference, from the SAME solve (a second solve doubled the step)
+        P = torch.empty(B, n, m, dtype=torch.float32, device=dev) if return_plan else None
+        C = torch.empty(B, n, m, dtype=torch.float32, device=dev) if return_plan else None
         with torch.cuda.device(dev):
             _lib.check(lib.shw_sinkhorn_forward_train(xc.data_ptr(), yc.data_ptr(), B, n, m, eps, max_iter, norm_p,
-                                                      cost_pow, thresh, ws.data_ptr(), cost.data_ptr(), _stream_ptr(dev)),
+                                                      cost_pow, thresh, ws.data_ptr(), cost.data_ptr(),
+                                                      P.data_ptr() if return_plan else None,
+                                                      C.data_ptr() if return_plan else None, _stream_ptr(dev)),
                        "shw_sinkhorn_forward_train")
         ctx.save_for_backward(xc, yc, ws)
         ctx.cfg = (B, n, m, eps, max_iter, norm_p, cost_pow)
-        return cost
+        if return_plan:
+            ctx.mark_non_differentiable(P, C)
+        return cost, P, C
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gP=None, _gC=None):
         lib = _lib.load()
         xc, yc, ws = ctx.saved_tensors
         B, n, m, eps, max_iter, norm_p, cost_pow = ctx.cfg
@@ -50,7 +58,7 @@ class _SinkhornCosts(torch.autograd.Function):
             _lib.check(lib.shw_sinkhorn_backward(xc.data_ptr(), yc.data_ptr(), B, n, m, eps, max_iter, norm_p, cost_pow,
                                                  ws.data_ptr(), gc.data_ptr(), gx.data_ptr(), gy.data_ptr(),
                                                  _stream_ptr(dev)), "shw_sinkhorn_backward")
-        return gx, gy, None, None, None, None, None
+        return gx, gy, None, None, None, None, None, None
 
 
 def sinkhorn_pair_costs(x, y, eps, max_iter, norm_p=2, cost_pow=1, thresh=1e-9, return_plan=False):
@@ -60,12 +68,10 @@ def sinkhorn_pair_costs(x, y, eps, max_iter, norm_p=2, cost_pow=1, thresh=1e-9, 
     if x.dim() != 3 or y.dim() != 3 or x.shape[0] != y.shape[0]:
         raise ValueError("x and y must be (B,n,3) and (B,m,3) with the same B")
     if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
-        cost = _SinkhornCosts.apply(x, y, float(eps), int(max_iter), int(norm_p), int(cost_pow), float(thresh))
-        P = C = None
-        if return_plan:                 # the dense outputs are plain tensors (no gradient flows through them here)
-            with torch.no_grad():
-                _, P, C = sinkhorn_pair_costs(x.detach(), y.detach(), eps, max_iter, norm_p, cost_pow, thresh, True)
-        return cost, P, C
+        # P and C come out of the same solve as plain tensors: they are marked non-differentiable (the reference's P and C
+        # are autograd-visible; a loss built on them gets no gradient here -- use the cost)
+        return _SinkhornCosts.apply(x, y, float(eps), int(max_iter), int(norm_p), int(cost_pow), float(thresh),
+                                    bool(return_plan))
     lib = _lib.load()
     B, n, _ = x.shape
     m = y.shape[1]

@@ -12,6 +12,9 @@ the hand-written gfx950 kernels.  CPU tensors are rejected: there is no fallback
 """
 from __future__ import annotations
 
+import threading
+from collections import OrderedDict
+
 import torch
 
 from . import _lib
@@ -71,10 +74,17 @@ class SSWWorkspace:
     zero-filled.  The user-visible results (per-pair losses, total) are NOT pool memory: they are one fresh
     (B+2)-float tensor per call, so holding on to a loss value across later calls is safe.
     Work on the buffers is ordered by the stream they were leased on (the stream is part of the key).  While
-    a HIP graph is being captured the pool is bypassed: buffers then belong to the graph's private memory."""
+    a HIP graph is being captured the pool is bypassed: buffers then belong to the graph's private memory.
+    Idle buffers are capped per shape (2) and in total (MAX_IDLE_BYTES, least recently used shapes evicted first); the
+    pool is guarded by a lock."""
 
-    _pools: dict = {}
+    _pools: "OrderedDict" = OrderedDict()      # key -> idle workspaces, least recently used key first
+    _lock = threading.Lock()                   # autograd may release leases from its own threads
     MAX_IDLE_PER_KEY = 2
+    # ADVICE r2: bounded per key only, every distinct shape pinned up to 1 GB (a training workspace at config 3 is 537 MB)
+    # that torch.cuda.empty_cache() cannot reclaim.  Idle buffers of ALL keys together stay below this many bytes: the
+    # least recently used shapes go back to torch's caching allocator first.
+    MAX_IDLE_BYTES = 4 << 30
 
     def __init__(self, key):
         dev, _stream, B, n, m, L, with_coef = key
@@ -84,6 +94,7 @@ class SSWWorkspace:
         self.slice_aux = torch.empty(B * L, dtype=torch.int32, device=dev)     # shift k* / median level / cut bits
         self.coef_s = torch.empty(B * L * n, dtype=torch.float32, device=dev) if with_coef else None
         self.coef_t = torch.empty(B * L * m, dtype=torch.float32, device=dev) if with_coef else None
+        self.nbytes = 8 * B * L + (4 * B * L * (n + m) if with_coef else 0)
 
     @classmethod
     def lease(cls, dev, B, n, m, L, with_coef):
@@ -92,22 +103,41 @@ class SSWWorkspace:
             ws = cls(key)
             ws.pooled = False
             return ws
-        idle = cls._pools.get(key)
-        if idle:
-            return idle.pop()
+        with cls._lock:
+            idle = cls._pools.get(key)
+            if idle:
+                cls._pools.move_to_end(key)
+                return idle.pop()
         return cls(key)
 
     def release(self):
         if not self.pooled:
             return
-        idle = SSWWorkspace._pools.setdefault(self.key, [])
-        if len(idle) < SSWWorkspace.MAX_IDLE_PER_KEY and all(ws is not self for ws in idle):
-            idle.append(self)
+        cls = SSWWorkspace
+        with cls._lock:
+            idle = cls._pools.setdefault(self.key, [])
+            cls._pools.move_to_end(self.key)
+            if len(idle) < cls.MAX_IDLE_PER_KEY and all(ws is not self for ws in idle):
+                idle.append(self)
+            total = sum(ws.nbytes for lst in cls._pools.values() for ws in lst)
+            while total > cls.MAX_IDLE_BYTES and cls._pools:
+                old_key = next(iter(cls._pools))                  # least recently used shape
+                lst = cls._pools[old_key]
+                if lst:
+                    total -= lst.pop().nbytes                     # back to torch's caching allocator
+                if not lst:
+                    del cls._pools[old_key]
+
+    @classmethod
+    def idle_bytes(cls):
+        with cls._lock:
+            return sum(ws.nbytes for lst in cls._pools.values() for ws in lst)
 
     @classmethod
     def clear(cls):
         """Drop every idle buffer (hands the memory back to torch's caching allocator)."""
-        cls._pools.clear()
+        with cls._lock:
+            cls._pools.clear()
 
 
 class _Lease:

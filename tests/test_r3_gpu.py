@@ -336,3 +336,49 @@ def test_small_grid_kernels_agree_with_the_throughput_kernels(shw):
             assert np.isfinite(gb).all()
             if same_shift.all():
                 assert np.abs(ga - gb).max() <= 1e-6 * np.abs(ga).max() + 1e-12, (key, f)
+
+
+# ------------------------------------------------------------------------------------------- pool cap, plan of one solve
+def test_workspace_pool_is_bounded_over_shapes(shw):
+    """idle workspaces were bounded per shape only -- every distinct (B, n, m, L) pinned its coefficient rows
+    until SSWWorkspace.clear().  The pool now evicts the least recently used shapes above MAX_IDLE_BYTES."""
+    ws = shw.ssw.SSWWorkspace
+    ws.clear()
+    old = ws.MAX_IDLE_BYTES
+    ws.MAX_IDLE_BYTES = 24 << 20
+    try:
+        gen = torch.Generator().manual_seed(1)
+        for n in (300, 400, 500, 600, 700, 800):                # 6 training shapes of 2*8*64*n*4 B = 1.2 .. 3.3 MB... x2 clouds
+            x = unit_cloud(gen, 8, n).cuda().requires_grad_(True)
+            y = unit_cloud(gen, 8, n).cuda()
+            shw.sliced_cost(x, y, directions(gen, 8, 256).cuda(), p=2).backward()
+            del x, y
+            assert ws.idle_bytes() <= ws.MAX_IDLE_BYTES
+        assert 0 < ws.idle_bytes() <= ws.MAX_IDLE_BYTES
+        assert all(key[3] != 300 for key in ws._pools)          # the oldest shape went first
+    finally:
+        ws.MAX_IDLE_BYTES = old
+        ws.clear()
+
+
+def test_sinkhorn_training_returns_the_plan_of_the_same_solve(shw, golden):
+    """with return_plan=True (the class default) a training call ran the whole solve twice.  P and C now come out
+    of the trajectory's last executed slot of the ONE solve: they must equal what the value-only entry point returns, sum to
+    the marginals like the reference's P (fixture G7), carry no gradient, and leave the cost's gradient as it was."""
+    g = golden("g7_sinkhorn.npz")
+    x, y = dev(g["x"]).requires_grad_(True), dev(g["y"]).requires_grad_(True)
+    crit = shw.log_Sinkhorn_Distance_Loss(eps=0.05, max_iter=60, batch_reduction="none", type_of_cost_norm="L2")
+    cost, P, C = crit(x, y, "cuda")
+    assert P is not None and not P.requires_grad and not C.requires_grad
+    with torch.no_grad():
+        cost0, P0, C0 = crit(x.detach(), y.detach(), "cuda")
+    assert torch.allclose(cost, cost0, rtol=1e-6) and torch.allclose(P, P0, rtol=1e-5, atol=1e-9) and torch.equal(C, C0)
+    assert rel(P.sum(-1).cpu().numpy(), g["P_rowsum_eps0.05_it60"]) < 5e-4
+    cost.sum().backward()
+    gx = x.grad.clone()
+    x2, y2 = dev(g["x"]).requires_grad_(True), dev(g["y"]).requires_grad_(True)
+    c2, P2, _ = shw.log_Sinkhorn_Distance_Loss(eps=0.05, max_iter=60, batch_reduction="none", type_of_cost_norm="L2",
+                                               return_plan=False)(x2, y2, "cuda")
+    assert P2 is None
+    c2.sum().backward()
+    assert torch.equal(gx, x2.grad)
