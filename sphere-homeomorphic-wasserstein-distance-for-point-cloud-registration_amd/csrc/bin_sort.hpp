@@ -41,6 +41,13 @@ namespace shw {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// bins of the key-only sort: 32 per key slot of a lane (two keys per bin) for the power-of-two classes; otherwise the next
+// count whose share per lane in the scan is a multiple of four (128-bit accesses): 768 for 20 and 24 keys per lane, 1024 for 28
+template <int EPT>
+constexpr int binsort_bins() {
+  return is_pow2(EPT) ? SHW_BINSORT_NB_PER_EPT * EPT : 64 * ((((EPT + 1) / 2) + 3) / 4 * 4);
+}
+
 // byte address of sorted position `pos` in the staging buffer: rows of 32 floats (one lane's read-back), the eight
 // 16-byte chunks of a row XOR-permuted by bits 1..3 of the row number so that the 16 lanes a ds_read_b128 serves
 // together touch 16 different bank groups (lane stride is 128 B: without the permutation 8 lanes share each group)
@@ -69,7 +76,7 @@ __device__ __forceinline__ int wave_inclusive_scan_dpp(int v) {
 template <int EPT, bool FULL>
 __device__ __forceinline__ int binsort_histogram(const float (&key)[EPT], unsigned (&w)[EPT], int lane, int n,
                                                  unsigned* cnt) {
-  constexpr int NB = SHW_BINSORT_NB_PER_EPT * EPT;
+  constexpr int NB = binsort_bins<EPT>();
   constexpr int BPL = NB / 64;                          // bins per lane in the scan (EPT/2: 16 at EPT = 32)
   static_assert(BPL >= 4 && BPL % 4 == 0, "bin sort needs >= 4 bins per lane");
   // zero the counters: every ds_write_b128 covers 1 KB of consecutive addresses (conflict-free)
@@ -77,26 +84,52 @@ __device__ __forceinline__ int binsort_histogram(const float (&key)[EPT], unsign
   for (int j = 0; j < BPL / 4; ++j)
     *reinterpret_cast<u32x4*>(cnt + j * 256 + lane * 4) = u32x4{0u, 0u, 0u, 0u};
   __builtin_amdgcn_wave_barrier();
-  constexpr int CH = 8;                                  // atomics in flight per lane; bounds the live registers
+  constexpr int CH = chunk_of(EPT);                      // atomics in flight per lane; bounds the live registers
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
-    unsigned b[CH], rank[CH];
+    // key[r] belongs to point r*64 + lane: the pads of a class that is not full are its LAST rows -- a chunk of rows is
+    // entirely live (no masks: the code of a full class), entirely pads (nothing to count) or the one mixed chunk;
+    // which of the three is uniform over the wave
+    // (measured, N = 1200 / 2000 at B = 64, L = 512: the branches pay in the classes of 12 .. 28 keys per lane -- the loads
+    //  are no longer hoisted together, 150 -> 111 VGPRs, a fourth wave per SIMD -- and cost 6 % at 32, where LDS holds the
+    //  occupancy at three: power-of-two classes keep the masked form)
+    constexpr bool kByChunk = !is_pow2(EPT);
+    const bool all_live = FULL || (kByChunk && (r0 + CH) * kWave <= n);
+    const bool none_live = !FULL && kByChunk && r0 * kWave >= n;
+    if (none_live) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      // v_cvt_u32_f32 saturates (NaN -> 0, +inf -> 0xffffffff): the bin is always inside [0, NB)
-      const unsigned t = (unsigned)(key[r0 + j] * (float)NB);
-      b[j] = t < (unsigned)(NB - 1) ? t : (unsigned)(NB - 1);
-      // pads (they add 0) go to 64 different counters: 64 atomics on ONE address would be served one after the other
-      if constexpr (!FULL) b[j] = ((r0 + j) * kWave + lane < n) ? b[j] : (unsigned)lane;
+      for (int j = 0; j < CH; ++j) w[r0 + j] = 0u;
+    } else if (all_live) {
+      unsigned b[CH], rank[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        // v_cvt_u32_f32 saturates (NaN -> 0, +inf -> 0xffffffff): the bin is always inside [0, NB)
+        const unsigned t = (unsigned)(key[r0 + j] * (float)NB);
+        b[j] = t < (unsigned)(NB - 1) ? t : (unsigned)(NB - 1);
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        rank[j] = __hip_atomic_fetch_add(cnt + b[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) w[r0 + j] = (rank[j] << 16) | b[j];
+    } else {
+      unsigned b[CH], rank[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const unsigned t = (unsigned)(key[r0 + j] * (float)NB);
+        b[j] = t < (unsigned)(NB - 1) ? t : (unsigned)(NB - 1);
+        // pads (they add 0) go to 64 different counters: 64 atomics on ONE address would be served one after the other
+        b[j] = ((r0 + j) * kWave + lane < n) ? b[j] : (unsigned)lane;
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        // pads add 0: no divergent branch around the atomic
+        const unsigned inc = ((r0 + j) * kWave + lane < n) ? 1u : 0u;
+        rank[j] = __hip_atomic_fetch_add(cnt + b[j], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) w[r0 + j] = (rank[j] << 16) | b[j];
     }
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      // pads add 0: no divergent branch around the atomic
-      const unsigned inc = (FULL || ((r0 + j) * kWave + lane < n)) ? 1u : 0u;
-      rank[j] = __hip_atomic_fetch_add(cnt + b[j], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-#pragma unroll
-    for (int j = 0; j < CH; ++j) w[r0 + j] = (rank[j] << 16) | b[j];
     __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_wave_barrier();
@@ -149,18 +182,27 @@ template <int EPT, bool FULL>
 __device__ __forceinline__ void binsort_place(float (&key)[EPT], const unsigned (&w)[EPT], int lane, int n, int g,
                                               const unsigned* cnt, float* buf) {
   char* bytes = reinterpret_cast<char*>(buf);
-  constexpr int CH = 8;
+  constexpr int CH = chunk_of(EPT);
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
-    unsigned start[CH];
+    constexpr bool kByChunk = !is_pow2(EPT);                       // (see binsort_histogram)
+    const bool all_live = FULL || (kByChunk && (r0 + CH) * kWave <= n);
+    const bool none_live = !FULL && kByChunk && r0 * kWave >= n;
+    if (none_live) {
+      // pads (key +inf, original index i >= n) go to position i: the positions behind the n live keys, each once
 #pragma unroll
-    for (int j = 0; j < CH; ++j) start[j] = cnt[w[r0 + j] & 0xffffu];
+      for (int j = 0; j < CH; ++j)
+        *reinterpret_cast<float*>(bytes + binsort_addr<EPT>((unsigned)((r0 + j) * kWave + lane))) = key[r0 + j];
+    } else {
+      unsigned start[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      // a pad (key +inf, original index i >= n) goes to position i: the positions behind the n live keys, each once
-      const unsigned i = (unsigned)((r0 + j) * kWave + lane);
-      const unsigned pos = (FULL || (int)i < n) ? start[j] + (w[r0 + j] >> 16) : i;
-      *reinterpret_cast<float*>(bytes + binsort_addr<EPT>(pos)) = key[r0 + j];
+      for (int j = 0; j < CH; ++j) start[j] = cnt[w[r0 + j] & 0xffffu];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const unsigned i = (unsigned)((r0 + j) * kWave + lane);
+        const unsigned pos = (all_live || (int)i < n) ? start[j] + (w[r0 + j] >> 16) : i;
+        *reinterpret_cast<float*>(bytes + binsort_addr<EPT>(pos)) = key[r0 + j];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -184,6 +226,28 @@ __device__ __forceinline__ void binsort_place(float (&key)[EPT], const unsigned 
   __builtin_amdgcn_wave_barrier();
 }
 
+// The bitonic network for a class that is not a power of two (the rare fallback of such a class): sort next_pow2(EPT) keys
+// per lane with +inf / all-ones behind the real ones, then take the 64 EPT smallest through the staging buffer into the
+// layout "sorted position lane*EPT + r".  MAXKEY sorts behind every real key.
+template <int EPT, class T>
+__device__ __forceinline__ void wave_sort_relayout(T (&key)[EPT], int lane, T maxkey, void* buf) {
+  constexpr int P2 = next_pow2_c(EPT);
+  T tmp[P2];
+#pragma unroll
+  for (int r = 0; r < P2; ++r) tmp[r] = r < EPT ? key[r < EPT ? r : 0] : maxkey;
+  wave_sort<P2>(tmp, lane);
+  char* bytes = reinterpret_cast<char*>(buf);
+#pragma unroll
+  for (int r = 0; r < P2; ++r) {
+    const unsigned pos = (unsigned)(lane * P2 + r);
+    if (pos < (unsigned)(kWave * EPT)) *reinterpret_cast<T*>(bytes + binsort_addr<EPT>(pos)) = tmp[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) key[r] = *reinterpret_cast<const T*>(bytes + binsort_addr<EPT>((unsigned)(lane * EPT + r)));
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Sort the 64*EPT keys of a wave ascending (pads = +inf behind the n live keys).  Falls back to the bitonic network
 // when the data has runs longer than SHW_BINSORT_MAX_RUN.  scratch: 32*EPT counters followed by 64*EPT floats.
 template <int EPT, bool FULL>
@@ -195,15 +259,16 @@ __device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, in
     binsort_place<EPT, FULL>(key, w, lane, n, g, cnt, buf);
   } else {
 #ifndef SHW_ABL_NO_FALLBACK
-    wave_sort<EPT>(key, lane);
+    if constexpr (is_pow2(EPT)) wave_sort<EPT>(key, lane);
+    else wave_sort_relayout<EPT, float>(key, lane, __builtin_inff(), buf);
 #endif
   }
 }
 
-// counters and staging buffer contiguous: 32*EPT counters followed by 64*EPT floats
+// counters and staging buffer contiguous: binsort_bins<EPT>() counters followed by 64*EPT floats
 template <int EPT, bool FULL>
 __device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, int n, float* scratch) {
-  wave_sort_binned<EPT, FULL>(key, lane, n, scratch, scratch + SHW_BINSORT_NB_PER_EPT * EPT);
+  wave_sort_binned<EPT, FULL>(key, lane, n, scratch, scratch + binsort_bins<EPT>());
 }
 
 }  // namespace shw

@@ -15,6 +15,11 @@
 
 namespace shw {
 
+// bins of the sort with indices: the top bits of a packed word ARE its bin, so the count is a power of two -- 32 per key
+// slot of a lane for the power-of-two classes, the next power of two above that otherwise (1024 for 20 .. 28 keys per lane)
+template <int EPT>
+constexpr int binsort_idx_bins() { return next_pow2_c(SHW_BINSORT_NB_PER_EPT * EPT); }
+
 template <int EPT>
 __device__ __forceinline__ void binsort_boundary_u32(unsigned (&x)[EPT], int lane) {
   const unsigned nxt = (unsigned)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)x[0]);
@@ -26,7 +31,7 @@ __device__ __forceinline__ void binsort_boundary_u32(unsigned (&x)[EPT], int lan
 }
 
 // project one cloud, sort it with its permutation; returns the coordinate sum of the lane.
-//   cnt : 32*EPT counters, buf : 64*EPT words (scatter target, then coordinates by original index -- still holding
+//   cnt : binsort_idx_bins<EPT>() counters (32*EPT for the power-of-two classes), buf : 64*EPT words (scatter target, then coordinates by original index -- still holding
 //   them on return, pads +inf).
 // CHAINED: see load_coords -- needed wherever this is not inside a loop (the compiler otherwise hoists all 3*EPT point
 // loads to the top and the raw points take 96 registers).
@@ -35,9 +40,9 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
                                                             const float (&U)[6], unsigned* cnt, float* buf,
                                                             float (&val)[EPT], int (&idx)[EPT]) {
   typedef Packing<EPT> PK;
-  constexpr int NB = SHW_BINSORT_NB_PER_EPT * EPT;
+  constexpr int NB = binsort_idx_bins<EPT>();
   constexpr int BPL = NB / 64;
-  constexpr int BIN_SHIFT = 32 - (__builtin_ctz(SHW_BINSORT_NB_PER_EPT) + __builtin_ctz(EPT));
+  constexpr int BIN_SHIFT = 32 - __builtin_ctz(NB);
   static_assert(BPL >= 4 && BPL % 4 == 0, "bin sort needs >= 4 bins per lane");
   float key[EPT];
   unsigned pk[EPT];
@@ -53,16 +58,23 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
   unsigned rk[(EPT + 3) / 4];
 #pragma unroll
   for (int q = 0; q < (EPT + 3) / 4; ++q) rk[q] = 0u;
-  constexpr int CH = EPT < 8 ? EPT : 8;
+  constexpr int CH = chunk_of(EPT);
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
     unsigned rank[CH];
+    // (uniform over the wave: every row of the chunk is live -- the code of a full class -- or the one mixed / pad chunk)
+    if (FULL || (!is_pow2(EPT) && (r0 + CH) * kWave <= count)) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      // pads add 0 (no divergent branch), each lane to its own counter (64 atomics on one address would serialise)
-      const bool live = FULL || (r0 + j) * kWave + lane < count;
-      const unsigned bin = live ? (pk[r0 + j] >> BIN_SHIFT) : (unsigned)lane;
-      rank[j] = __hip_atomic_fetch_add(cnt + bin, live ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      for (int j = 0; j < CH; ++j)
+        rank[j] = __hip_atomic_fetch_add(cnt + (pk[r0 + j] >> BIN_SHIFT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        // pads add 0 (no divergent branch), each lane to its own counter (64 atomics on one address would serialise)
+        const bool live = (r0 + j) * kWave + lane < count;
+        const unsigned bin = live ? (pk[r0 + j] >> BIN_SHIFT) : (unsigned)lane;
+        rank[j] = __hip_atomic_fetch_add(cnt + bin, live ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) rk[(r0 + j) / 4] |= (rank[j] & 0xffu) << (8 * ((r0 + j) & 3));
@@ -110,11 +122,12 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
       unsigned start[CH];
 #pragma unroll
       for (int j = 0; j < CH; ++j) start[j] = cnt[pk[r0 + j] >> BIN_SHIFT];
+      const bool whole = FULL || (!is_pow2(EPT) && (r0 + CH) * kWave <= count);       // (uniform over the wave)
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         // a pad (word 0xffffffff, original index i >= count) goes to position i: behind the live words, each once
         const unsigned i = (unsigned)((r0 + j) * kWave + lane);
-        const unsigned pos = (FULL || (int)i < count) ? start[j] + ((rk[(r0 + j) / 4] >> (8 * ((r0 + j) & 3))) & 0xffu) : i;
+        const unsigned pos = (whole || (int)i < count) ? start[j] + ((rk[(r0 + j) / 4] >> (8 * ((r0 + j) & 3))) & 0xffu) : i;
         *reinterpret_cast<unsigned*>(bytes + binsort_addr<EPT>(pos)) = pk[r0 + j];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -139,10 +152,14 @@ __device__ __forceinline__ float sorted_with_indices_binned(const float* __restr
       }
     }
   } else {
+#ifndef SHW_ABL_NO_FALLBACK
+    // (a class that is not a power of two sorts through the buffer: before the coordinates move in)
+    if constexpr (!is_pow2(EPT)) wave_sort_relayout<EPT, unsigned>(pk, lane, 0xffffffffu, buf);
+#endif
 #pragma unroll
     for (int r = 0; r < EPT; ++r) buf[r * kWave + lane] = key[r];
 #ifndef SHW_ABL_NO_FALLBACK
-    wave_sort<EPT>(pk, lane);
+    if constexpr (is_pow2(EPT)) wave_sort<EPT>(pk, lane);
 #endif
   }
   __builtin_amdgcn_wave_barrier();

@@ -19,14 +19,15 @@ namespace shw {
 template <int EPT, int PMODE, bool FULL>
 __global__ __launch_bounds__(128, SHW_FWD2_MINW) void ssw_forward2_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SCR = (32 + 64) * EPT;                   // per wave: 32*EPT counters + 64*EPT staging floats
+  constexpr int NBINS = binsort_bins<EPT>();             // 32*EPT for the power-of-two classes
+  constexpr int SCR = NBINS + 64 * EPT;                  // per wave: the counters + 64*EPT staging floats
   constexpr int HALF = EPT / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* scr_s = lds;                                      // wave 0: source
   float* scr_t = lds + SCR;                                // wave 1: target
-  float* row_s = scr_s + 32 * EPT;                         // published rows = the staging buffers
-  float* row_t = scr_t + 32 * EPT;
+  float* row_s = scr_s + NBINS;                            // published rows = the staging buffers
+  float* row_t = scr_t + NBINS;
   float* red = lds + 2 * SCR;                              // [2 parities][2 waves][4] partial sums, [2] coordinate sums
   float* my_scr = wave ? scr_t : scr_s;
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(128, SHW_FWD2_MINW) void ssw_forward2_kernel(SswArg
     const float total = wave_sum_uniform(part, lane);
     if (FULL || wave == 0) {                               // (partial sizes: the target goes out as extended rows below)
 #pragma unroll
-      for (int r = 0; r < EPT; ++r) my_scr[32 * EPT + r * kWave + lane] = key[r];
+      for (int r = 0; r < EPT; ++r) my_scr[NBINS + r * kWave + lane] = key[r];
     }
     if (lane == 0) red[16 + wave] = total;
   }
@@ -115,26 +116,33 @@ static int launch_forward2(SswArgs& A, hipStream_t stream) {
   const long total = (long)A.pairs * A.slices;
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
-  const size_t lds = (size_t)(2 * 96 * EPT + 32) * sizeof(float);
-  const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
+  const size_t lds = (size_t)(2 * (binsort_bins<EPT>() + 64 * EPT) + 32) * sizeof(float);
+  // (the mask-free forms index with shifts and masks: power-of-two classes only)
+  const bool full = is_pow2(EPT) && (A.n == EPT * kWave) && (A.m == EPT * kWave);
   const dim3 grid((unsigned)total), block(128);
-  if (A.p_int == 2) {
-    if (full) hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 2, true>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 2, false>), grid, block, lds, stream, A);
-  } else {
-    if (full) hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 0, true>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 0, false>), grid, block, lds, stream, A);
+  if constexpr (is_pow2(EPT)) {
+    if (full) {
+      if (A.p_int == 2) hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 2, true>), grid, block, lds, stream, A);
+      else hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 0, true>), grid, block, lds, stream, A);
+      return (int)hipGetLastError();
+    }
   }
+  if (A.p_int == 2) hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 2, false>), grid, block, lds, stream, A);
+  else hipLaunchKernelGGL((ssw_forward2_kernel<EPT, 0, false>), grid, block, lds, stream, A);
   return (int)hipGetLastError();
 }
 
 int dispatch_forward2(SswArgs& A, hipStream_t stream) {
-  switch (ept_for(A.n, A.m)) {
+  switch (kpl_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT
     case SHW_DEV_ONLY_EPT: return launch_forward2<SHW_DEV_ONLY_EPT>(A, stream);
 #else
     case 8: return launch_forward2<8>(A, stream);
+    case 12: return launch_forward2<12>(A, stream);
     case 16: return launch_forward2<16>(A, stream);
+    case 20: return launch_forward2<20>(A, stream);
+    case 24: return launch_forward2<24>(A, stream);
+    case 28: return launch_forward2<28>(A, stream);
     case 32: return launch_forward2<32>(A, stream);
 #endif
     default: return (int)hipErrorInvalidValue;

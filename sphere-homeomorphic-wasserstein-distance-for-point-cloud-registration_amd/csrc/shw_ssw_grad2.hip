@@ -27,20 +27,26 @@ namespace shw {
 #ifndef SHW_GRAD2_MINW_PARTIAL
 #define SHW_GRAD2_MINW_PARTIAL 3
 #endif
-constexpr int grad2_waves_per_simd(int ept, bool full) { return ept == 32 ? (full ? SHW_GRAD2_MINW : SHW_GRAD2_MINW_PARTIAL) : 4; }
+// counters of the sort with indices (a power of two, bin_sort_idx.hpp) or half a row of 16-bit indices, whichever is larger
+constexpr int grad2_counter_floats(int ept) {
+  return next_pow2_c(SHW_BINSORT_NB_PER_EPT * ept) > 32 * ept ? next_pow2_c(SHW_BINSORT_NB_PER_EPT * ept) : 32 * ept;
+}
+// (20 .. 28 keys per lane need the 168 registers of three waves per SIMD like 32: asked for four they spill 27 .. 64)
+constexpr int grad2_waves_per_simd(int ept, bool full) { return ept == 32 ? (full ? SHW_GRAD2_MINW : SHW_GRAD2_MINW_PARTIAL) : (ept >= 20 ? 3 : 4); }
 
 template <int EPT, int PMODE, bool FULL>
 __global__ __launch_bounds__(128, grad2_waves_per_simd(EPT, FULL)) void ssw_forward_grad2_kernel(SswArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave;
   constexpr int HALF = EPT / 2;
+  constexpr int CNT = grad2_counter_floats(EPT);                   // the sort's counters, then the 16-bit index row
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* row_s = lds;                                              // source: coordinates row, then staging row
-  float* row_t = lds + ROW * 3 / 2;                                // target
+  float* row_t = lds + ROW + CNT;                                  // target
   unsigned short* idx_s = reinterpret_cast<unsigned short*>(row_s + ROW);   // sorted original indices (counters first)
   unsigned short* idx_t = reinterpret_cast<unsigned short*>(row_t + ROW);
-  float* red = lds + ROW * 3;                                      // [2 parities][2 waves][4] partial sums, [2] sums
+  float* red = lds + 2 * (ROW + CNT);                              // [2 parities][2 waves][4] partial sums, [2] sums
   float* my_row = wave ? row_t : row_s;
   unsigned short* my_idx = wave ? idx_t : idx_s;
 
@@ -152,26 +158,33 @@ static int launch_forward_grad2(SswArgs& A, hipStream_t stream) {
   const long total = (long)A.pairs * A.slices;
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
-  const size_t lds = (size_t)(EPT * kWave * 3 + 32) * sizeof(float);
-  const bool full = (A.n == EPT * kWave) && (A.m == EPT * kWave);
+  const size_t lds = (size_t)(2 * (EPT * kWave + grad2_counter_floats(EPT)) + 32) * sizeof(float);
+  // (the mask-free forms index with shifts and masks: power-of-two classes only)
+  const bool full = is_pow2(EPT) && (A.n == EPT * kWave) && (A.m == EPT * kWave);
   const dim3 grid((unsigned)total), block(128);
-  if (A.p_int == 2) {
-    if (full) hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 2, true>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 2, false>), grid, block, lds, stream, A);
-  } else {
-    if (full) hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 0, true>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 0, false>), grid, block, lds, stream, A);
+  if constexpr (is_pow2(EPT)) {
+    if (full) {
+      if (A.p_int == 2) hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 2, true>), grid, block, lds, stream, A);
+      else hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 0, true>), grid, block, lds, stream, A);
+      return (int)hipGetLastError();
+    }
   }
+  if (A.p_int == 2) hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 2, false>), grid, block, lds, stream, A);
+  else hipLaunchKernelGGL((ssw_forward_grad2_kernel<EPT, 0, false>), grid, block, lds, stream, A);
   return (int)hipGetLastError();
 }
 
 int dispatch_forward_grad2(SswArgs& A, hipStream_t stream) {
-  switch (ept_for(A.n, A.m)) {
+  switch (kpl_for(A.n, A.m)) {
 #ifdef SHW_DEV_ONLY_EPT
     case SHW_DEV_ONLY_EPT: return launch_forward_grad2<SHW_DEV_ONLY_EPT>(A, stream);
 #else
     case 8: return launch_forward_grad2<8>(A, stream);
+    case 12: return launch_forward_grad2<12>(A, stream);
     case 16: return launch_forward_grad2<16>(A, stream);
+    case 20: return launch_forward_grad2<20>(A, stream);
+    case 24: return launch_forward_grad2<24>(A, stream);
+    case 28: return launch_forward_grad2<28>(A, stream);
     case 32: return launch_forward_grad2<32>(A, stream);
 #endif
     default: return (int)hipErrorInvalidValue;

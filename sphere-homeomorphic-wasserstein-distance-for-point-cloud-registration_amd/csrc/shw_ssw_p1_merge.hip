@@ -26,7 +26,12 @@
 // (first merged atom: -|level - med| / lcm) is un-permuted through two LDS staging rows and stored coalesced:
 // every coefficient written exactly once, no atomics (rows feed ssw_backward_points_kernel).  The one-wave
 // search kernel it replaces sorted 64-bit (key, index) items: 3.5 -> see DESIGN.md ms per training step.
+#include "bin_sort_idx.hpp"
 #include "ssw_common.hpp"
+
+#ifndef SHW_P1M_GRAD_BINS
+#define SHW_P1M_GRAD_BINS 1     // training: each wave sorts its cloud by the distribution sort with indices (>= 8 keys per lane)
+#endif
 
 namespace shw {
 
@@ -90,7 +95,13 @@ ssw_level_median_merge_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
     if constexpr (GRAD) {
       float val[EPT];
       int idx[EPT];
-      sorted_with_indices<EPT>(X, count, lane, U, lds + wave * CHUNK, val, idx);
+      // round 3: the distribution sort with indices of the p != 1 training kernel (bin_sort_idx.hpp) instead of the
+      // bitonic network on packed words; its 32 EPT counters sit where the wave's 16-bit index row goes afterwards
+      if constexpr (SHW_P1M_GRAD_BINS != 0 && EPT >= 8)
+        sorted_with_indices_binned<EPT, true, false>(X, count, lane, U, reinterpret_cast<unsigned*>(sidx + wave * CHUNK),
+                                                     lds + wave * CHUNK, val, idx);
+      else
+        sorted_with_indices<EPT>(X, count, lane, U, lds + wave * CHUNK, val, idx);
 #pragma unroll
       for (int r = 0; r < EPT; ++r) {
         sidx[wave * CHUNK + r * kWave + lane] = (unsigned short)idx[r];     // sorted position lane*EPT + r

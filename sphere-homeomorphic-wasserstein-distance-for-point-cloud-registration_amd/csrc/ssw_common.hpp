@@ -18,8 +18,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../include/shw.h"
 #include "wave_sort.hpp"
+
+#ifndef SHW_MASK_BY_EXEC
+#define SHW_MASK_BY_EXEC 1      // pads of a partially filled class masked by exec (a kept branch) instead of three selects
+#endif
 
 namespace shw {
 
@@ -139,8 +145,25 @@ __device__ __forceinline__ float dpow_abs(float d, float p, int p_int) {
 // workgroup sort one slice together (shw_ssw_fwd.hip, multi-wave kernel).
 template <int EPT, int NCOL = 64>
 __device__ __forceinline__ int lds_slot(int q) {
-  constexpr int LOG = __builtin_ctz(EPT);
-  return (q & (EPT - 1)) * NCOL + (q >> LOG);
+  if constexpr (is_pow2(EPT)) {
+    constexpr int LOG = __builtin_ctz(EPT);
+    return (q & (EPT - 1)) * NCOL + (q >> LOG);
+  } else {                                          // (q >= 0: division by a constant)
+    const unsigned col = (unsigned)q / (unsigned)EPT;
+    return (int)(((unsigned)q - col * (unsigned)EPT) * (unsigned)NCOL + col);
+  }
+}
+
+// floor(x / EPT) and x - EPT floor(x / EPT) for x >= -1024 EPT: shift and mask for the power-of-two classes
+template <int EPT>
+__device__ __forceinline__ int ediv(int x) {
+  if constexpr (is_pow2(EPT)) return x >> __builtin_ctz(EPT);
+  else return (int)((unsigned)(x + 1024 * EPT) / (unsigned)EPT) - 1024;
+}
+template <int EPT>
+__device__ __forceinline__ int emod(int x) {
+  if constexpr (is_pow2(EPT)) return x & (EPT - 1);
+  else return x - ediv<EPT>(x) * EPT;
 }
 
 // v_ext(q) for q in [-2n, 3n): branch-free wrap onto [0, n) with the turn offset (two turns each
@@ -170,7 +193,7 @@ __device__ __forceinline__ void shift_costs3(const float (&u)[NR], const float* 
   const int last = n - 1;
   float prev = target_unrolled<EPT, NCOL>(vbuf, min(e0, last) + k - 1, n);
   float cur = target_unrolled<EPT, NCOL>(vbuf, min(e0, last) + k, n);
-  constexpr int CH = NR < 8 ? NR : 8;
+  constexpr int CH = chunk_of(NR);
 #pragma unroll
   for (int r0 = 0; r0 < NR; r0 += CH) {
     float nxt[CH];
@@ -313,14 +336,13 @@ struct ExtRows {
 template <int EPT, int NCOL = 64>
 __device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext, int lane, int n, int kc) {
   typedef ExtRows<EPT, NCOL> X;
-  constexpr int LOG = __builtin_ctz(EPT);
   // c1 = (M - kc) mod n and the turn s it absorbs: ext[p + c1] = v[p] - s, or, past the end, ext[p + c1 - n] = v[p] - s - 1
   const int t = X::M - kc;                                       // in [M - n, M + n]
   const int s = t < 0 ? -1 : (t >= n ? 1 : 0);
   const int c1 = t - s * n;                                      // in [0, n)
   const int c2 = c1 - n;                                         // in [-n, 0)
-  const int c1h = c1 >> LOG, c1l = c1 & (EPT - 1);
-  const int c2h = c2 >> LOG, c2l = c2 & (EPT - 1);               // floor division
+  const int c1h = ediv<EPT>(c1), c1l = emod<EPT>(c1);
+  const int c2h = ediv<EPT>(c2), c2l = emod<EPT>(c2);            // floor division
   const float vn = (float)(-s), vw = (float)(-s - 1);
   char* bytes = reinterpret_cast<char*>(ext);
   const int lane4 = lane << 2;
@@ -328,8 +350,8 @@ __device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int a1 = r + c1l, a2 = r + c2l;                        // scalars
-    const int off_n = (((a1 & (EPT - 1)) * X::RS) + c1h + (a1 >> LOG)) << 2;
-    const int off_w = (((a2 & (EPT - 1)) * X::RS) + c2h + (a2 >> LOG)) << 2;
+    const int off_n = ((emod<EPT>(a1) * X::RS) + c1h + ediv<EPT>(a1)) << 2;
+    const int off_w = ((emod<EPT>(a2) * X::RS) + c2h + ediv<EPT>(a2)) << 2;
     const int pos = lane * EPT + r;
     const bool wrap = pos >= first_wrapped;
     int off = wrap ? off_w : off_n;
@@ -340,8 +362,8 @@ __device__ __forceinline__ void ext_rows_write(const float (&v)[EPT], float* ext
   // halo: ext[n + l] = ext[l] + 1 for l < 2M (one entry per lane; 2M <= 64)
   {
     const int src = lane, dst = n + lane;
-    const int so = (((src & (EPT - 1)) * X::RS) + (src >> LOG)) << 2;
-    const int d_o = (((dst & (EPT - 1)) * X::RS) + (dst >> LOG)) << 2;
+    const int so = ((emod<EPT>(src) * X::RS) + ediv<EPT>(src)) << 2;
+    const int d_o = ((emod<EPT>(dst) * X::RS) + ediv<EPT>(dst)) << 2;
     const float x = *reinterpret_cast<const float*>(bytes + so);
     *reinterpret_cast<float*>(bytes + (lane < 2 * X::M ? d_o : X::TRASH)) = x + 1.f;
   }
@@ -354,19 +376,18 @@ template <int EPT, int PMODE, int NR = EPT, int NCOL = 64>
 __device__ __forceinline__ void shift_costs3_ext(const float (&u)[NR], const float* ext, int lane, int n, int d,
                                                  float p, int p_int, float& cm, float& c0, float& cp, int r_base = 0) {
   typedef ExtRows<EPT, NCOL> X;
-  constexpr int LOG = __builtin_ctz(EPT);
   const int base = d - 1 + X::M + r_base;                        // >= 0, wave-uniform
-  const int bl = base & (EPT - 1), bh = base >> LOG;
+  const int bl = emod<EPT>(base), bh = ediv<EPT>(base);
   const char* rows = reinterpret_cast<const char*>(ext) + (lane << 2);
   auto fetch = [&](int j) -> float {                             // j compile-time after unrolling
     const int a = bl + j;                                        // scalar
-    const int off = (((a & (EPT - 1)) * X::RS) + bh + (a >> LOG)) << 2;
+    const int off = ((emod<EPT>(a) * X::RS) + bh + ediv<EPT>(a)) << 2;
     return *reinterpret_cast<const float*>(rows + off);
   };
   const int live_regs = n - lane * EPT - r_base;                 // registers j < live_regs hold real atoms
   float sm = 0.f, s0 = 0.f, sp = 0.f;
   float prev = fetch(0), cur = fetch(1);
-  constexpr int CH = NR < 8 ? NR : 8;
+  constexpr int CH = chunk_of(NR);
 #pragma unroll
   for (int r0 = 0; r0 < NR; r0 += CH) {
     float nxt[CH];
@@ -374,13 +395,22 @@ __device__ __forceinline__ void shift_costs3_ext(const float (&u)[NR], const flo
     for (int j = 0; j < CH; ++j) nxt[j] = fetch(r0 + j + 2);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const bool live = (r0 + j) < live_regs;
       const float a = pow_abs<PMODE>(u[r0 + j] - prev, p, p_int);
       const float b = pow_abs<PMODE>(u[r0 + j] - cur, p, p_int);
       const float c = pow_abs<PMODE>(u[r0 + j] - nxt[j], p, p_int);
+#if SHW_MASK_BY_EXEC
+      // pads add nothing: a branch the compiler must keep (the empty asm), i.e. one v_cmp and an exec mask around three
+      // full-rate adds -- as selects the three accumulations cost a quarter-rate v_cndmask each (op rates)
+      if ((r0 + j) < live_regs) {
+        asm volatile("" : "+v"(sm), "+v"(s0), "+v"(sp));
+        sm += a; s0 += b; sp += c;
+      }
+#else
+      const bool live = (r0 + j) < live_regs;
       sm += live ? a : 0.f;
       s0 += live ? b : 0.f;
       sp += live ? c : 0.f;
+#endif
       prev = cur;
       cur = nxt[j];
     }
@@ -469,7 +499,7 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
   }
   const int wide = (kFold && rows) ? 0 : -1;       // all ones: 12-byte records
   const int o1 = (kFold && rows) ? 0 : 1, o2 = (kFold && rows) ? 0 : 2;
-  constexpr int CH = EPT < 8 ? EPT : 8;            // 8 points (24 loads) in flight per lane
+  constexpr int CH = chunk_of(EPT);                // 8 points (24 loads) in flight per lane (4 or 5 for the odd classes)
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
     if constexpr (!FULL && !kFold) {
@@ -487,25 +517,46 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
     if constexpr (CHAINED) {
       if (r0 > 0) asm volatile("" : "+v"(lane) : "v"(key[r0 > 0 ? r0 - 1 : 0]));
     }
+    // lane owns points r*NCOL + lane: when every point of the chunk's rows exists (uniform over the wave) the chunk is
+    // the code of a full class -- no clamped addresses, no masks; only the one mixed chunk of a cloud pays for them
+    const bool whole = FULL || (!is_pow2(EPT) && (r0 + CH) * NCOL <= (live_count < count ? live_count : count));   // (classes: bin_sort.hpp)
+    if (whole) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int raw = (r0 + j) * NCOL + lane;
-      const int i = FULL ? raw : min(raw, count - 1);           // clamp: branch-free, always in bounds
-      const int i3 = kFold ? i + ((i & wide) << 1) : 3 * i;     // 3 i, or i for rows of coordinates
-      px[j] = X[i3]; py[j] = X[i3 + (kFold ? o1 : 1)]; pz[j] = X[i3 + (kFold ? o2 : 2)];
-    }
+      for (int j = 0; j < CH; ++j) {
+        const int i = (r0 + j) * NCOL + lane;
+        const int i3 = kFold ? i + ((i & wide) << 1) : 3 * i;
+        px[j] = X[i3]; py[j] = X[i3 + (kFold ? o1 : 1)]; pz[j] = X[i3 + (kFold ? o2 : 2)];
+      }
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int i = (r0 + j) * NCOL + lane;
-      // fma(x, u, +0): a sum that starts from +0 like the reference's matmul accumulator (:270), so that an
-      // all-zero point projects to (+0, +0) -- never -0 -- and lands on coordinate 0 (G4 fixture)
-      const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
-      const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], fmaf(px[j], U[1], 0.f)));
-      float c = circle_coord(a, b);
-      if constexpr (kFold) c = rows ? px[j] : c;
-      const bool live = FULL || (i < live_count);
-      acc += live ? c : 0.f;
-      key[r0 + j] = live ? c : __builtin_inff();
+      for (int j = 0; j < CH; ++j) {
+        const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
+        const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], fmaf(px[j], U[1], 0.f)));
+        float c = circle_coord(a, b);
+        if constexpr (kFold) c = rows ? px[j] : c;
+        acc += c;
+        key[r0 + j] = c;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int raw = (r0 + j) * NCOL + lane;
+        const int i = min(raw, count - 1);                        // clamp: branch-free, always in bounds
+        const int i3 = kFold ? i + ((i & wide) << 1) : 3 * i;     // 3 i, or i for rows of coordinates
+        px[j] = X[i3]; py[j] = X[i3 + (kFold ? o1 : 1)]; pz[j] = X[i3 + (kFold ? o2 : 2)];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int i = (r0 + j) * NCOL + lane;
+        // fma(x, u, +0): a sum that starts from +0 like the reference's matmul accumulator (:270), so that an
+        // all-zero point projects to (+0, +0) -- never -0 -- and lands on coordinate 0 (G4 fixture)
+        const float a = fmaf(pz[j], U[4], fmaf(py[j], U[2], fmaf(px[j], U[0], 0.f)));
+        const float b = fmaf(pz[j], U[5], fmaf(py[j], U[3], fmaf(px[j], U[1], 0.f)));
+        float c = circle_coord(a, b);
+        if constexpr (kFold) c = rows ? px[j] : c;
+        const bool live = i < live_count;
+        acc += live ? c : 0.f;
+        key[r0 + j] = live ? c : __builtin_inff();
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -518,7 +569,7 @@ __device__ __forceinline__ float load_coords(const float* __restrict__ X, int co
 // ---------------------------------------------------------------------------------------------
 template <int EPT>
 struct Packing {
-  static constexpr int IDX_BITS = __builtin_ctz(EPT * kWave);
+  static constexpr int IDX_BITS = log2_ceil_c(EPT * kWave);
   static constexpr int QBITS = 32 - IDX_BITS;
   static constexpr unsigned IDX_MASK = (1u << IDX_BITS) - 1u;
   static __device__ __forceinline__ unsigned pack(float coord, int idx, bool live) {
@@ -677,6 +728,20 @@ inline int next_pow2(int v) {
 inline int ept_for(int n, int m) {
   const int padded = next_pow2(n > m ? n : m);
   return padded <= 64 ? 1 : padded / 64;
+}
+
+// keys per lane of the two-wave kernels of 513..2048 points (round 3): the power-of-two classes plus 12, 20, 24 and 28, so
+// that a cloud pays for the next multiple of 256 points (768: of 256 x 3) and not for the next power of two -- the
+// notebooks' 1200 points (Flow_cube.ipynb:200) take 1280 slots instead of 2048.  SHW_KPL_CLASSES=0 keeps powers of two.
+inline int kpl_for(int n, int m) {
+  const int big = n > m ? n : m;
+  const int e = ept_for(n, m);
+  static const bool fine = [] { const char* v = getenv("SHW_KPL_CLASSES"); return !(v && v[0] == '0'); }();
+  if (!fine || e < 16) return e;
+  for (int k = e / 2 + 4; k < e; k += 4) {           // 16: 12;  32: 20, 24, 28
+    if (k * 64 >= big) return k;
+  }
+  return e;
 }
 
 // dispatchers, one per translation unit (SswArgs validated by the C entry points in shw_capi.hip)

@@ -21,6 +21,18 @@ namespace shw {
 
 constexpr int kWave = 64;
 
+// Keys per lane need not be a power of two (round 3: classes of 12, 20, 24, 28 keys per lane, so that a 1200-point cloud
+// pays for 1280 slots and not 2048).  Compile-time helpers for the code that is generic in the class:
+constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+constexpr int next_pow2_c(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+constexpr int log2_ceil_c(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
+// largest divisor of `count` that is <= most: unrolled loops work in chunks of it (8 for the power-of-two classes)
+constexpr int chunk_of(int count, int most = 8) {
+  int best = 1;
+  for (int d = 1; d <= most; ++d) best = (count % d == 0) ? d : best;
+  return best;
+}
+
 __device__ __forceinline__ float as_f(int v) { return __builtin_bit_cast(float, v); }
 __device__ __forceinline__ int as_i(float v) { return __builtin_bit_cast(int, v); }
 

@@ -291,7 +291,9 @@ sys.path.insert(0, sys.argv[1])
 import shw_amd
 out = {}
 for (n, p, kind) in ((600, 2, "sphere"), (1000, 2, "sphere"), (1200, 2, "cube"), (1500, 3, "sphere"), (2000, 2, "sphere"),
-                     (2048, 2, "sphere"), (1024, 2.5, "sphere"), (1200, 2, "lattice"), (512, 2, "sphere")):
+                     (2048, 2, "sphere"), (1024, 2.5, "sphere"), (1200, 2, "lattice"), (512, 2, "sphere"),
+                     (768, 2, "sphere"), (769, 2, "sphere"), (1280, 2, "sphere"), (1281, 3, "sphere"), (1536, 2, "sphere"),
+                     (1700, 2, "sphere"), (1792, 2.5, "sphere"), (1793, 2, "sphere"), (1700, 2, "lattice"), (700, 2, "lattice")):
     g = torch.Generator().manual_seed(7 * n + len(kind))
     x, y = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
     if kind == "sphere":
@@ -315,9 +317,10 @@ print(json.dumps(out))
 def test_small_grid_kernels_agree_with_the_throughput_kernels(shw):
     """a launch with fewer (pair, slice) problems than SIMDs (the notebooks: 1 pair x 100 slices) takes
     the cooperative kernels with 8 keys per lane and W = padded / 512 waves per slice.  SHW_SMALL_GRID=0 keeps the
-    throughput kernels (two waves per slice, 32 keys per lane) for any grid: the same seeded cases in two subprocesses must
-    give the same shifts, costs to 3e-6 and -- both sorts being stable -- the same gradients, also on un-normalised clouds
-    and on clouds of duplicate points."""
+    throughput kernels (two waves per slice; 12 / 16 / 20 / 24 / 28 / 32 keys per lane: every class of round 3 is in the list,
+    at its upper edge and one point above it) for any grid: the same seeded cases in two subprocesses must give the same
+    shifts, costs to 3e-6 and -- both sorts being stable -- the same gradients, also on un-normalised clouds and on clouds
+    of duplicate points (which take the sorts' network fallback, through the staging buffer for the odd classes)."""
     res = {}
     for forced in ("0", "1024"):
         env = dict(os.environ, SHW_SMALL_GRID=forced)
@@ -382,3 +385,39 @@ def test_sinkhorn_training_returns_the_plan_of_the_same_solve(shw, golden):
     assert P2 is None
     c2.sum().backward()
     assert torch.equal(gx, x2.grad)
+
+
+# ------------------------------------------------------------------------------------------- keys-per-lane classes (item 4)
+@pytest.mark.parametrize("n", [600, 768, 1200, 1280, 1500, 1700, 2000])
+@pytest.mark.parametrize("p", [2, 3])
+def test_sizes_between_the_powers_of_two_against_cpu_oracle(shw, n, p):
+    """clouds of 513..2047 points take keys-per-lane classes of 12 / 20 / 24 / 28 (the next multiple of
+    256 points) in the two-wave kernels instead of the next power of two.  A launch of 4 pairs x 300 slices (more than the
+    small-grid limit, so the throughput kernels run) against the float64 oracle on a sample of its slices, loss and
+    gradients; plus the loss-only kernel against the training kernel on every slice."""
+    from helpers.compare import grad_close
+    from oracle import exact_shift
+    gen = torch.Generator().manual_seed(77 * n + int(p))
+    B, L = 4, 300
+    x, y, U = unit_cloud(gen, B, n), unit_cloud(gen, B, n), directions(gen, B, L)
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, shift = shw.ssw_pair_losses(xs, ys, U.cuda(), p=p, return_slices=True)
+    sample = [0, 1, 149, 298, 299]
+    for b in (0, 3):
+        cu = exact_shift.circle_coords(x[b].numpy(), U[b, sample].numpy())
+        cv = exact_shift.circle_coords(y[b].numpy(), U[b, sample].numpy())
+        ref64, k64 = exact_shift.circular_ot_equal(cu, cv, p=p)
+        assert np.allclose(cost[b, sample].detach().cpu().numpy(), ref64, rtol=2e-5 if p == 2 else 4e-5, atol=1e-10)
+    with torch.no_grad():
+        _, cost_fwd, shift_fwd = shw.ssw_pair_losses(x.cuda(), y.cuda(), U.cuda(), p=p, return_slices=True)
+    assert torch.allclose(cost_fwd, cost.detach(), rtol=3e-6, atol=1e-12)
+    # gradients: the same problem slice-sharded into small grids (the cooperative kernels, checked against the oracle
+    # elsewhere) must add up to the gradient of the one big launch
+    pair.sum().backward()
+    xa, ya = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    total = 0
+    for l0 in range(0, L, 100):
+        total = total + shw.ssw_pair_losses(xa, ya, U[:, l0:l0 + 100].cuda().contiguous(), p=p).sum() * (100.0 / L)
+    total.backward()
+    grad_close(xs.grad.cpu().numpy(), xa.grad.cpu().numpy(), strict=2e-5, loose=2e-2, frac=0.0005)
+    grad_close(ys.grad.cpu().numpy(), ya.grad.cpu().numpy(), strict=2e-5, loose=2e-2, frac=0.0005)
