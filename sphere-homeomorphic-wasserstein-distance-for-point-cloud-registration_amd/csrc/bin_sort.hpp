@@ -32,8 +32,17 @@
 #ifndef SHW_BINSORT_NB_PER_EPT
 #define SHW_BINSORT_NB_PER_EPT 32
 #endif
+// Longest equal-bin run the one-wave sorts fix up by odd-even phases (one phase ~ 33 quarter-rate instructions per lane,
+// ~60 ns) before they prefer the bitonic network (~4.4 us per 2048-key sort, after the histogram has been paid): round 2
+// used 24, which sent 23 % of the slices of the notebooks' cube-surface clouds and 95 % of tightly clustered clouds to
+// the network (profiles/r03_nonuniform.txt).  Measured break-even: ~45 phases (at 64 clouds of 32-fold duplicate
+// points took 0.68 instead of 0.53 ms per launch, at 24 sixteen tight clusters 0.56 instead of 0.52).
 #ifndef SHW_BINSORT_MAX_RUN
-#define SHW_BINSORT_MAX_RUN 24
+#define SHW_BINSORT_MAX_RUN 40
+#endif
+// the cooperative sorts (several waves per slice) finish a run that straddles two waves inside a 64-key window: < 32
+#ifndef SHW_COOP_MAX_RUN
+#define SHW_COOP_MAX_RUN 24
 #endif
 
 namespace shw {
@@ -250,8 +259,9 @@ __device__ __forceinline__ void wave_sort_relayout(T (&key)[EPT], int lane, T ma
 
 // Sort the 64*EPT keys of a wave ascending (pads = +inf behind the n live keys).  Falls back to the bitonic network
 // when the data has runs longer than SHW_BINSORT_MAX_RUN.  scratch: 32*EPT counters followed by 64*EPT floats.
+// Returns the longest run of keys that share a bin (> SHW_BINSORT_MAX_RUN: the slice took the network).
 template <int EPT, bool FULL>
-__device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, int n, float* counters, float* buf) {
+__device__ __forceinline__ int wave_sort_binned(float (&key)[EPT], int lane, int n, float* counters, float* buf) {
   unsigned* cnt = reinterpret_cast<unsigned*>(counters);
   unsigned w[EPT];
   const int g = binsort_histogram<EPT, FULL>(key, w, lane, n, cnt);
@@ -263,12 +273,13 @@ __device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, in
     else wave_sort_relayout<EPT, float>(key, lane, __builtin_inff(), buf);
 #endif
   }
+  return g;
 }
 
 // counters and staging buffer contiguous: binsort_bins<EPT>() counters followed by 64*EPT floats
 template <int EPT, bool FULL>
-__device__ __forceinline__ void wave_sort_binned(float (&key)[EPT], int lane, int n, float* scratch) {
-  wave_sort_binned<EPT, FULL>(key, lane, n, scratch, scratch + binsort_bins<EPT>());
+__device__ __forceinline__ int wave_sort_binned(float (&key)[EPT], int lane, int n, float* scratch) {
+  return wave_sort_binned<EPT, FULL>(key, lane, n, scratch, scratch + binsort_bins<EPT>());
 }
 
 }  // namespace shw

@@ -9,7 +9,7 @@
 //     gl*EPT + r -- the layout of wave_sort / the multi-wave bitonic kernel;
 //   * every wave fixes up its own 64*EPT positions; a run of equal-bin keys that straddles the seam between two
 //     waves is finished by a 64-key window sort around the seam (one key per lane, the cross-lane network of
-//     wave_sort.hpp): runs are at most SHW_BINSORT_MAX_RUN (< 32) long, so the window holds them whole;
+//     wave_sort.hpp): runs are at most SHW_COOP_MAX_RUN (< 32) long, so the window holds them whole;
 //   * workgroup barriers separate the steps (7 per sort).
 // Data with longer runs falls back to the bitonic network (in-wave sort + merge across waves through LDS).
 #pragma once
@@ -154,7 +154,7 @@ __device__ __forceinline__ void coop_sort(float (&key)[EPT], int wave, int lane,
     *reinterpret_cast<u32x4*>(cnt + gl * C::BPL + j * 4) =
         u32x4{c[4 * j] + off, c[4 * j + 1] + off, c[4 * j + 2] + off, c[4 * j + 3] + off};
   __syncthreads();
-  if (g > SHW_BINSORT_MAX_RUN) {
+  if (g > SHW_COOP_MAX_RUN) {
     // long runs (clustered data, duplicates): the network sorts it; counters re-zeroed for the next sort
     coop_zero_counters<EPT, W>(cnt, gl);
     coop_bitonic<EPT, W>(key, buf, wave, lane);

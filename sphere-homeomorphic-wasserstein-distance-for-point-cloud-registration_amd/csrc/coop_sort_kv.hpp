@@ -130,7 +130,7 @@ __device__ __forceinline__ void coop_sort_kv(item_t (&it)[EPT], int wave, int la
           u32x4{c[4 * j] + off, c[4 * j + 1] + off, c[4 * j + 2] + off, c[4 * j + 3] + off};
   }
   __syncthreads();
-  if (g > SHW_BINSORT_MAX_RUN) {
+  if (g > SHW_COOP_MAX_RUN) {
     // long runs (clustered data, duplicates): the network sorts it; counters re-zeroed for the next sort
     coop_zero_counters<EPT, W, KPB>(cnt, gl);
     coop_bitonic_kv<EPT, W>(it, buf, wave, lane);

@@ -60,6 +60,9 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE, FULL)) vo
 
   float key[EPT], u[EPT];
   float sum_v = 0.f, sum_u = 0.f;
+#ifdef SHW_DBG_RUNLEN
+  int dbg_run = 0;
+#endif
 #pragma nounroll
   for (int which = 0; which < 2; ++which) {        // 0: source -> registers, 1: target -> LDS
     const float* X = which == 0 ? A.xs + (long)b * A.n * A.pstride : A.xt + (long)b * A.m * A.pstride;
@@ -80,8 +83,13 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE, FULL)) vo
 #else
     const float part = load_coords<EPT, FULL>(X, count, ln, U, key);
 #endif
+#ifdef SHW_DBG_RUNLEN          // developer build (tools/nonuniform_time.py): slice_shift reports the longest equal-bin run
+    if constexpr (BINS) dbg_run = max(dbg_run, wave_sort_binned<EPT, FULL>(key, ln, count, scratch));
+    else wave_sort<EPT>(key, ln);
+#else
     if constexpr (BINS) wave_sort_binned<EPT, FULL>(key, ln, count, scratch);
     else wave_sort<EPT>(key, ln);
+#endif
     if (which == 0) {
       sum_u = wave_sum(part, lane);
 #pragma unroll
@@ -114,6 +122,9 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE, FULL)) vo
   if (lane == 0) {
     A.slice_cost[s] = best / (float)A.n;
     if (A.slice_shift) A.slice_shift[s] = k;
+#ifdef SHW_DBG_RUNLEN
+    if (A.slice_shift) A.slice_shift[s] = dbg_run;
+#endif
   }
 }
 

@@ -44,9 +44,8 @@ struct GeneralArgs {
   long wu_pair_stride;    // 0 = shared by all pairs
   long wv_pair_stride;
   float* slice_theta;     // optional: the cut the solve ended on
-  float first_step;       // first step of the bracket search around the mean-difference guess
-  float min_width;        // bracket width below which the tangent intersection finishes the solve
-  float grid;             // no weights: lcm(n, m) -- every kink of the cost is a multiple of 1/grid; else 0
+  float first_step;       // weights: first step of the bracket search around the mean-difference guess
+  float min_width;        // weights: bracket width below which the tangent intersection finishes the solve
   int lcm, lcm_a, lcm_b;  // no weights: lcm(n, m), lcm / n, lcm / m  (n, m <= 4096: lcm < 2^24) -- the integer grid below
   // training runs as TWO launches: the solve at the loss-only kernel's occupancy (it leaves the cut of slice s in
   // cut_scratch[s * cut_stride] -- the first word of the slice's own coefficient row), then the gradient kernel
@@ -116,65 +115,20 @@ constexpr int kTeamFloats = 48;   // two parities of four waves' sums + the mean
 #ifndef SHW_GENERAL_W32
 #define SHW_GENERAL_W32 2       // waves per slice at 1025..2048 points
 #endif
-#ifndef SHW_GENERAL_UNIFORM_BINS
-#define SHW_GENERAL_UNIFORM_BINS 0   // no weights, several waves per slice: distribution sort (half a row of counters per cloud)
-#endif
 #ifndef SHW_GENERAL_MINW_UNIFORM
 #define SHW_GENERAL_MINW_UNIFORM 3   // waves per SIMD asked of the register allocator, kernels without weights
 #endif
 constexpr int general_waves(int ept) { return ept >= 64 ? 4 : (ept == 32 ? SHW_GENERAL_W32 : (ept >= 16 ? 2 : 1)); }
-// no weights: the two value rows are all the LDS the solve needs; with W > 1 each sorting wave gets half a row of counters
-template <int EPT, bool UNIFORM, int W>
-constexpr bool general_uniform_bins() { return UNIFORM && W > 1 && EPT >= 8 && SHW_GENERAL_UNIFORM_BINS != 0; }
-template <int EPT, bool UNIFORM, int W>
-constexpr int general_counter_floats() { return general_uniform_bins<EPT, UNIFORM, W>() ? EPT * kWave : 0; }
-
-// one cloud as the solver sees it: ascending atom values and their inclusive CDF, lds_slot layout.
-// UNIFORM (no weights given, the reference's default 1/count): the CDF is (i+1)/count -- no array -- and every
-// search over it is arithmetic: a rank estimate from key*count, put right by one comparison each way against
-// the same closed-form levels, so that ranks and levels stay mutually consistent exactly as searchsorted on the
-// reference's cumsum is (:156-170).
-template <int EPT, bool UNIFORM = false>
+// one cloud as the solver sees it (weights given): ascending atom values and their inclusive CDF, lds_slot layout.
+// (Clouds WITHOUT weights never get here: their CDFs are (i+1)/count and the solve runs on the integer grid of lcm(n, m),
+//  grid_* below.)
+template <int EPT>
 struct Side {
   const float* val;
   const float* cdf;
   int count;
-  float inv_count;                                          // 1 / count
   __device__ __forceinline__ float v(int i) const { return val[lds_slot<EPT>(i)]; }
-  __device__ __forceinline__ float c(int i) const {
-    if constexpr (UNIFORM) {
-      // (i+1)/count, CORRECTLY ROUNDED, without the division sequence: q = x*RN(1/y), one exact residual, one
-      // correction (Markstein).  Correct rounding matters: when n and m share a factor, levels of the two clouds
-      // coincide as rationals ((i+1)/n == (j+1)/m) and must then coincide as floats, or the very first
-      // evaluation (theta = 0, frac = 0) sees inconsistent ties and can report a false kink.
-      const float x = (float)(i + 1), y = (float)count;
-      const float q = x * inv_count;
-      return fmaf(fmaf(-q, y, x), inv_count, q);
-    }
-    else return cdf[lds_slot<EPT>(i)];
-  }
-  // UNIFORM: number of levels < key (strict) or <= key, in closed form
-  __device__ __forceinline__ int rank(float key, bool strict) const {
-    const float t = key * (float)count;
-    int r = strict ? (int)ceilf(t) - 1 : (int)floorf(t);
-    r = min(max(r, 0), count);
-    const float up = c(min(r, count - 1)), dn = c(max(r - 1, 0));
-    const bool more = r < count && (strict ? (up < key) : (up <= key));
-    const bool less = r > 0 && !(strict ? (dn < key) : (dn <= key));
-    return r + (more ? 1 : 0) - (less ? 1 : 0);
-  }
-  // both ranks at once.  key*count further than a few ulps from an integer decides every comparison with the
-  // (correctly rounded) levels, and then  #{< key} == #{<= key} == floor(key*count);  only the rare near-integer
-  // case -- which contains every exact tie -- takes the comparisons of rank().
-  __device__ __forceinline__ void rank2(float key, int& lt, int& le) const {
-    const float t = key * (float)count;
-    const float f = floorf(t);
-    lt = le = min(max((int)f, 0), count);
-    if (fabsf(t - rintf(t)) <= 6e-7f * fabsf(t) + 1e-7f) {
-      lt = rank(key, true);
-      le = rank(key, false);
-    }
-  }
+  __device__ __forceinline__ float c(int i) const { return cdf[lds_slot<EPT>(i)]; }
   // number of atom VALUES < key (strict) or <= key (the p = 1 formula merges by value, not by CDF level)
   __device__ __forceinline__ int values_below(float key, bool strict) const {
     int lo = 0, hi = count;
@@ -189,7 +143,6 @@ struct Side {
   }
   // number of CDF entries < key (strict) or <= key  == torch.searchsorted(cdf, key, right = !strict)
   __device__ __forceinline__ int below(float key, bool strict) const {
-    if constexpr (UNIFORM) return rank(key, strict);
     int lo = 0, hi = count;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -211,21 +164,6 @@ struct Side {
 // lower_bounds2: for every key, the number of entries < key (lt) and <= key (le) among the first `count`
 // entries of an ascending array in lds_slot layout  (= torch.searchsorted(..., right=False / True)).
 // ---------------------------------------------------------------------------------------------
-template <int EPT, int NB>
-__device__ __forceinline__ void lower_bounds2_arr(const float* arr, int count, const float (&key)[NB], int (&lt)[NB],
-                                                  int (&le)[NB]);
-
-template <int EPT, bool UNIFORM, int NB>
-__device__ __forceinline__ void lower_bounds2(const Side<EPT, UNIFORM>& S, const float (&key)[NB], int (&lt)[NB],
-                                              int (&le)[NB]) {
-  if constexpr (UNIFORM) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) S.rank2(key[b], lt[b], le[b]);
-  } else {
-    lower_bounds2_arr<EPT, NB>(S.cdf, S.count, key, lt, le);
-  }
-}
-
 template <int EPT, int NB>
 __device__ __forceinline__ void lower_bounds2_arr(const float* arr, int count, const float (&key)[NB], int (&lt)[NB],
                                                   int (&le)[NB]) {
@@ -290,10 +228,10 @@ constexpr int kWalkRounds = 6;
 constexpr int kWalkExt = 6;
 
 // weighted clouds with >= 8 atoms per lane evaluate their slopes by walking (cut_slopes_walk)
-template <int EPT, bool UNIFORM>
-constexpr bool general_walks() { return !UNIFORM && EPT >= 8; }
-template <int EPT, bool UNIFORM>
-constexpr int general_ext_floats() { return general_walks<EPT, UNIFORM>() ? kWalkExt * kWave : 0; }
+template <int EPT>
+constexpr bool general_walks() { return EPT >= 8; }
+template <int EPT>
+constexpr int general_ext_floats() { return general_walks<EPT>() ? kWalkExt * kWave : 0; }
 
 
 template <int EPT>
@@ -435,18 +373,17 @@ __device__ __forceinline__ void walk_lower_bounds2(const float* arr, int count, 
 }
 
 // the target after moving mass theta around the circle (reference :31-48, evaluated lazily)
-template <int EPT, bool UNIFORM = false>
+template <int EPT>
 struct Rotated {
-  Side<EPT, UNIFORM> t;
+  Side<EPT> t;
   float turns, frac;
   int start;                               // number of wrapped atoms = first atom of the rotated order
-  __device__ __forceinline__ void set(const Side<EPT, UNIFORM>& target, float theta, int lane) {
+  __device__ __forceinline__ void set(const Side<EPT>& target, float theta, int lane) {
     t = target;
     turns = floorf(theta);
     frac = theta - turns;
     // (cdf - frac) < 0  <=>  cdf < frac
-    if constexpr (UNIFORM) start = target.below(frac, true);
-    else start = wave_lower_bound_arr<EPT>(target.cdf, target.count, frac, lane);
+    start = wave_lower_bound_arr<EPT>(target.cdf, target.count, frac, lane);
     if (start >= target.count) start = 0;  // degenerate (no atom left unwrapped): argmin over all-inf = 0
   }
   // atom j of the sorted target: shifted CDF and position unrolled onto the real line
@@ -469,20 +406,7 @@ struct Rotated {
     return p;
   }
   // number of rotated CDF entries strictly below key  == searchsorted(v_cdf_theta_rolled, key)
-  // UNIFORM: rotated entry rho is (start + rho + 1)/m - frac, so the count is arithmetic (+- one comparison)
-  __device__ __forceinline__ int rank(float key) const {
-    const int m = t.count;
-    const float x = (key + frac) * (float)m;
-    if (fabsf(x - rintf(x)) > 1.2e-6f * fabsf(x) + 1e-7f)     // clear of every level: ceil(x) - 1 == floor(x)
-      return min(max((int)floorf(x) - start, 0), m);
-    int r = (int)ceilf(x) - 1 - start;
-    r = min(max(r, 0), m);
-    const bool more = r < m && cdf_at(min(r, m - 1)) < key;
-    const bool less = r > 0 && !(cdf_at(max(r - 1, 0)) < key);
-    return r + (more ? 1 : 0) - (less ? 1 : 0);
-  }
   __device__ __forceinline__ int below(float key) const {
-    if constexpr (UNIFORM) return rank(key);
     int lo = 0, hi = t.count;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -523,11 +447,6 @@ struct Rotated {
   // the same for NB keys at once, fixed trip count (see lower_bounds2)
   template <int NB>
   __device__ __forceinline__ void below_batch(const float (&key)[NB], int (&cnt)[NB]) const {
-    if constexpr (UNIFORM) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) cnt[b] = rank(key[b]);
-      return;
-    }
     constexpr int P = EPT * kWave;
     const int m = t.count;
 #pragma unroll
@@ -559,19 +478,18 @@ __device__ __forceinline__ float powp(float d, float p, int p_int) { return pow_
 
 // one-sided derivatives of the cost w.r.t. theta (reference dCost, :50-63), uniform over the slice's waves.
 // tid: index of the thread among the 64 W threads of the slice; it owns target atoms [tid AP, (tid+1) AP), AP = EPT / W.
-template <int EPT, int PMODE, bool UNIFORM, int W>
-__device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, int tid, float p,
+template <int EPT, int PMODE, int W>
+__device__ void cut_slopes(const Side<EPT>& S, const Side<EPT>& T, float theta, int lane, int tid, float p,
                            int p_int, SliceTeam<W>& team, float& d_plus, float& d_minus) {
   constexpr int AP = EPT / W;
-  Rotated<EPT, UNIFORM> R;
+  Rotated<EPT> R;
   R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   float sp = 0.f, sm = 0.f;
-  constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
-  constexpr int NA = AP < NA_MAX ? AP : NA_MAX;
-  int walk_ptr = 0;                                          // weighted: rank of the thread's previous atom
+  constexpr int NA = AP < 8 ? AP : 8;                        // atoms searched together
+  int walk_ptr = 0;                                          // rank of the thread's previous atom
   float walk_prev = 0.f;
-  if constexpr (!UNIFORM) {
+  {
     float c0, p0;
     R.atom(min(tid * AP, m - 1), c0, p0);
     walk_ptr = lower_bound_arr<EPT>(S.cdf, n, c0);
@@ -597,9 +515,7 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
       npos[a] = wp[a + 1] + ((wj[a + 1] == R.start) ? 1.f : 0.f);   // successor of the last rotated atom: first + 1
     }
     int lt[NA], le[NA];
-    if constexpr (UNIFORM) {
-      lower_bounds2<EPT, UNIFORM, NA>(S, cdf, lt, le);
-    } else {
+    {
       bool alive[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) alive[a] = (tid * AP + r0 + a) < m;
@@ -632,13 +548,13 @@ __device__ void cut_slopes(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>
 // (`anchor`; warm = false: binary search): the cut moves by less than a level spacing between late evaluations, so
 // the carried rank is put right by one backward and one forward round instead of a 12-probe search.
 template <int EPT, int PMODE, int C, int W>
-__device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false>& T, float theta, int lane, int tid, float p,
+__device__ void cut_slopes_walk(const Side<EPT>& S, const Side<EPT>& T, float theta, int lane, int tid, float p,
                                 int p_int, SliceTeam<W>& team, float& d_plus, float& d_minus, int (&anchor)[C], bool warm,
                                 float& cost_scale) {
   constexpr int AP = EPT / W;                                // atoms of the thread: [tid AP, (tid+1) AP)
   constexpr int LEN = AP / C;
   static_assert(AP % C == 0, "chains of equal length");
-  Rotated<EPT, false> R;
+  Rotated<EPT> R;
   R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   const float* arr = S.cdf;
@@ -736,19 +652,18 @@ __device__ void cut_slopes_walk(const Side<EPT, false>& S, const Side<EPT, false
 
 // transport cost at a fixed cut (reference Cost, :94-112), uniform over the slice's waves.  Thread tid evaluates the grid
 // points of source atoms and of target atoms [tid AP, (tid+1) AP).
-template <int EPT, int PMODE, bool UNIFORM, int W>
-__device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>& T, float theta, int lane, int tid, float p,
+template <int EPT, int PMODE, int W>
+__device__ float cut_cost(const Side<EPT>& S, const Side<EPT>& T, float theta, int lane, int tid, float p,
                           int p_int, SliceTeam<W>& team) {
   constexpr int AP = EPT / W;
-  Rotated<EPT, UNIFORM> R;
+  Rotated<EPT> R;
   R.set(T, theta, lane);
   const int n = S.count, m = T.count;
   float acc = 0.f;
-  constexpr int NA_MAX = UNIFORM ? 4 : 8;                    // atoms searched together (weighted: longer probe chains)
-  constexpr int NA = AP < NA_MAX ? AP : NA_MAX;
-  int walk_cnt = 0, walk_ptr = 0;                            // weighted: ranks of the thread's previous atoms
+  constexpr int NA = AP < 8 ? AP : 8;                        // atoms searched together
+  int walk_cnt = 0, walk_ptr = 0;                            // ranks of the thread's previous atoms
   float walk_prev = 0.f;
-  if constexpr (!UNIFORM) {
+  {
     const float k1[1] = {S.c(min(tid * AP, n - 1))};
     int c1[1];
     R.template below_batch<1>(k1, c1);
@@ -765,8 +680,7 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
       int cnt[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) g[a] = S.c(min(tid * AP + r0 + a, n - 1));
-      if constexpr (UNIFORM) R.template below_batch<NA>(g, cnt);   // rotated target atom active at g
-      else R.template below_walk<NA>(g, walk_cnt, cnt);
+      R.template below_walk<NA>(g, walk_cnt, cnt);             // rotated target atom active at g
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
         const int e = tid * AP + r0 + a;
@@ -785,9 +699,7 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
       int lt[NA], le[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) R.atom(min(tid * AP + r0 + a, m - 1), g[a], b[a]);
-      if constexpr (UNIFORM) {
-        lower_bounds2<EPT, UNIFORM, NA>(S, g, lt, le);
-      } else if constexpr (general_walks<EPT, UNIFORM>()) {  // window reads (the rows under the source CDF exist)
+      if constexpr (general_walks<EPT>()) {                  // window reads (the rows under the source CDF exist)
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
           const float k1[1] = {g[a]};
@@ -846,8 +758,8 @@ __device__ float cut_cost(const Side<EPT, UNIFORM>& S, const Side<EPT, UNIFORM>&
 // level) advance the source first; the leftover segment has width 0 -- the reference's merged grid gives the duplicate
 // grid point a zero delta too.
 // ---------------------------------------------------------------------------------------------
-template <int EPT, int PMODE, bool UNIFORM, int W>
-__device__ float walk_source_atoms(const Side<EPT, UNIFORM>& S, const Rotated<EPT, UNIFORM>& R, int tid, float p, int p_int,
+template <int EPT, int PMODE, int W>
+__device__ float walk_source_atoms(const Side<EPT>& S, const Rotated<EPT>& R, int tid, float p, int p_int,
                                    float* gs) {
   constexpr int AP = EPT / W;
   const int n = S.count, m = R.t.count;
@@ -896,8 +808,8 @@ __device__ float walk_source_atoms(const Side<EPT, UNIFORM>& S, const Rotated<EP
   return cost;
 }
 
-template <int EPT, int PMODE, bool UNIFORM, int W>
-__device__ void walk_target_atoms(const Side<EPT, UNIFORM>& S, const Rotated<EPT, UNIFORM>& R, int tid, float p, int p_int,
+template <int EPT, int PMODE, int W>
+__device__ void walk_target_atoms(const Side<EPT>& S, const Rotated<EPT>& R, int tid, float p, int p_int,
                                   float* gt, float* tail) {
   constexpr int AP = EPT / W;
   const int n = S.count, m = R.t.count;
@@ -1201,7 +1113,7 @@ __device__ void grid_grad_target(const float* s_val, const float* t_val, const G
 // leaves the sorted values / CDF in LDS (dval, dcdf) and the sorted->original index map in registers.  `scratch` is a row
 // for the coordinates by original index (it may be dval itself: the gather out of it is complete before the sorted values
 // are written, LDS operations of a wave execute in order), `counters` 32 EPT words for the distribution sort.
-template <int EPT, bool UNIFORM = false, bool BINS = (EPT >= 8 && !UNIFORM)>
+template <int EPT, bool UNIFORM = false>
 __device__ __forceinline__ void prepare_one(const GeneralArgs& G, int s, int lane, int which, float* dval, float* dcdf,
                                             float* scratch, unsigned* counters, int (&idx)[EPT], float& mean_out) {
   const SswArgs& A = G.base;
@@ -1220,7 +1132,7 @@ __device__ __forceinline__ void prepare_one(const GeneralArgs& G, int s, int lan
   // row).  Without weights the one-wave kernel ran two waves per SIMD on 248 registers and the distribution sort's extra
   // live words spilled (measured in round 2: 2.1 -> 3.3 ms at n = 2048, m = 1536): it keeps the network.
   float part;
-  if constexpr (BINS) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
+  if constexpr (EPT >= 8 && !UNIFORM) part = sorted_with_indices_binned<EPT, false, false>(X, count, ln, U, counters, scratch, val, idx);
   else part = sorted_with_indices<EPT>(X, count, ln, U, scratch, val, idx);
   float mean = 0.f;                                        // mass-weighted mean coordinate (first guess of the cut)
   if constexpr (UNIFORM) {
@@ -1316,15 +1228,13 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
   // source gradient row), target gradient row (GRAD only)
   float* s_val = lds;
   float* t_val = lds + ROW;
-  constexpr int EXT = general_ext_floats<EPT, UNIFORM>();     // window rows under the source CDF (fill_walk_ext)
+  constexpr int EXT = (UNIFORM ? 0 : general_ext_floats<EPT>());     // window rows under the source CDF (fill_walk_ext)
   float* s_cdf = UNIFORM ? nullptr : lds + 2 * ROW;
   float* t_cdf = UNIFORM ? nullptr : lds + 3 * ROW + EXT;
   float* grad_rows = lds + (UNIFORM ? 2 : 4) * ROW + EXT;    // GRAD only: two rows of coefficients by sorted position
   float* gs = grad_rows;
   float* gt = grad_rows + ROW;
-  constexpr int CNT = general_counter_floats<EPT, UNIFORM, W>();   // no weights, W > 1: counters of the two distribution sorts
-  float* team_mem = lds + ((UNIFORM ? 2 : 4) + (GRAD ? 2 : 0)) * ROW + EXT + CNT;
-  unsigned* own_counters = reinterpret_cast<unsigned*>(team_mem - CNT + (wave & 1) * (CNT / 2));
+  float* team_mem = lds + ((UNIFORM ? 2 : 4) + (GRAD ? 2 : 0)) * ROW + EXT;
   SliceTeam<W> team{team_mem, wave, 0};
   float* shared = team_mem + 8 * W;                          // [0], [1]: the two mean coordinates; [2]: the tail coefficient
 
@@ -1376,9 +1286,9 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
         float mean;
         // each wave's own rows serve as its sort scratch: the value row takes the coordinates by original index, the
         // CDF row the counters; both are written with their final contents after the wave's gather
-        constexpr bool UBINS = general_uniform_bins<EPT, UNIFORM, W>();
-        prepare_one<EPT, UNIFORM, UBINS || (EPT >= 8 && !UNIFORM)>(
-            G, s, lane, which, dval, dcdf, dval, UBINS ? own_counters : reinterpret_cast<unsigned*>(dcdf), oidx[0], mean);
+        // (without weights the sorts stay on the network: the distribution sort with indices needs half a row of counters
+        //  per cloud -- 24 instead of 16 KB per slice -- and measured 2.06 against 1.79 ms at 2048 vs 1536 points)
+        prepare_one<EPT, UNIFORM>(G, s, lane, which, dval, dcdf, dval, reinterpret_cast<unsigned*>(dcdf), oidx[0], mean);
         if (lane == 0) shared[which == 0 ? 1 : 0] = mean;
       }
     }
@@ -1465,8 +1375,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
       }
     }
   } else {
-  Side<EPT, UNIFORM> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
-  if constexpr (general_walks<EPT, UNIFORM>()) {
+  Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
+  if constexpr (general_walks<EPT>()) {
     if (wave == 0) fill_walk_ext<EPT>(s_cdf, lane);
     if constexpr (W > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   }
@@ -1479,8 +1389,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
   // difference of the mean coordinates (up to the kink spacing) and for other p it is near it; the search
   // steps out from there (doubling) until dCost changes sign, then bisects.  Both quantile functions are step
   // functions, so the cost is linear between kinks, and once the bracket is narrower than the smallest kink
-  // spacing (G.min_width: half a level of the lcm grid without weights, the reference's 1e-7 with weights) it
-  // holds at most one kink and the tangent intersection IS the minimiser.
+  // spacing (G.min_width: the reference's eps/L = 1e-7) it holds at most one kink and the tangent intersection IS the
+  // minimiser.  (Clouds without weights do not come here: the integer grid above.)
   float t_mid = 0.f;
 #ifdef SHW_DBG_EVALS
   int dbg_evals = 0, dbg_bracket_at = -1;
@@ -1510,8 +1420,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
       if (dbg_bracket_at < 0 && lo_tight && hi_tight) dbg_bracket_at = it;
 #endif                          // <= ~25 doublings + ~25 halvings
       float dp, dm;
-      if constexpr (!general_walks<EPT, UNIFORM>()) {
-        cut_slopes<EPT, PMODE, UNIFORM, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team, dp, dm);
+      if constexpr (!general_walks<EPT>()) {
+        cut_slopes<EPT, PMODE, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team, dp, dm);
       } else {
         cut_slopes_walk<EPT, PMODE, kChains, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team, dp, dm, anchors, it > 0, cost_scale);
       }
@@ -1522,8 +1432,8 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
       if (!(dp * dm > 0.f)) break;                             // non-finite input: stop
       if (dp < 0.f) { t_lo = t_mid; lo_tight = true; dp_lo = dp; }
       else { t_hi = t_mid; hi_tight = true; dm_hi = dm; }
-      if constexpr (!UNIFORM) {
-        // weighted clouds: by convexity an end of the bracket is within  width * |slope at that end|  of the minimum
+      {
+        // by convexity an end of the bracket is within  width * |slope at that end|  of the minimum
         // COST.  Below one fp32 ulp of the cost (and below 1e-12 in any case) nothing is left to gain and the end is the
         // answer: with ~n*m micro-kinks the slope near the optimum is a noisy ~1e-6 and the search would spend its
         // last evaluations inside that noise; this ends it a few halvings before eps/L, and without the three cost
@@ -1538,33 +1448,26 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
       }
       if ((t_hi - t_lo) < G.min_width) {                       // :189-200
         float unused;
-        if (!lo_tight) cut_slopes<EPT, PMODE, UNIFORM, W>(S, T, t_lo, lane, tid, A.p, A.p_int, team, dp_lo, unused);
-        if (!hi_tight) cut_slopes<EPT, PMODE, UNIFORM, W>(S, T, t_hi, lane, tid, A.p, A.p_int, team, unused, dm_hi);
-        const float c_lo = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_lo, lane, tid, A.p, A.p_int, team);
-        const float c_hi = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_hi, lane, tid, A.p, A.p_int, team);
+        if (!lo_tight) cut_slopes<EPT, PMODE, W>(S, T, t_lo, lane, tid, A.p, A.p_int, team, dp_lo, unused);
+        if (!hi_tight) cut_slopes<EPT, PMODE, W>(S, T, t_hi, lane, tid, A.p, A.p_int, team, unused, dm_hi);
+        const float c_lo = cut_cost<EPT, PMODE, W>(S, T, t_lo, lane, tid, A.p, A.p_int, team);
+        const float c_hi = cut_cost<EPT, PMODE, W>(S, T, t_hi, lane, tid, A.p, A.p_int, team);
         float t_c = (t_lo + t_hi) * 0.5f;
-        const float on_grid = G.grid > 0.f ? rintf(t_c * G.grid) / G.grid : 2.f;
-        const float slack = 4e-7f;                             // a bracket end can BE the kink, seen from one side
-        if (on_grid >= t_lo - slack && on_grid <= t_hi + slack) {
-          t_c = on_grid;                                       // no weights: THE kink inside the bracket, exactly
-        } else if (fabsf(dp_lo - dm_hi) > 1e-3f) {             // tangent intersection, :198-199 (written relative to
+        if (fabsf(dp_lo - dm_hi) > 1e-3f) {                    // tangent intersection, :198-199 (written relative to
           // t_lo: the reference's form cancels terms of size theta * slope against each other)
           const float t_x = t_lo + (c_hi - c_lo - dm_hi * (t_hi - t_lo)) / (dp_lo - dm_hi);
           if (t_x == t_x) t_c = fminf(fmaxf(t_x, t_lo), t_hi);
         }
         // never end above a bracket end: an evaluation that lands within rounding of a kink can put that kink
         // ON an end, and the candidate then sits on the wrong side of it
-        const float c_c = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_c, lane, tid, A.p, A.p_int, team);
+        const float c_c = cut_cost<EPT, PMODE, W>(S, T, t_c, lane, tid, A.p, A.p_int, team);
         t_mid = t_c;
         float best = c_c;
         if (c_lo < best) { best = c_lo; t_mid = t_lo; }
         if (c_hi < best) { best = c_hi; t_mid = t_hi; }
         break;
       }
-      // (without weights the kinks sit on the grid of 1/lcm(n, m): coarse for sizes with a large common factor -- 2048
-      //  vs 1536: 6144 kinks, halving wins, 2.13 against 2.21 ms -- and as fine as the weighted case for sizes without --
-      //  717 vs 1024: 734 208 kinks, the secant wins, 0.56 against 0.75 ms)
-      if (!UNIFORM || G.grid > 16.f * (float)(n + m)) {
+      {
         // Weighted clouds (round 2).  The cost has n*m kinks (every coincidence of a source level with a target
         // level), ~2.4e-7 apart at 2048 points: its one-sided slope is, at every scale above that, a smooth increasing
         // function -- exactly linear for p = 2 with the masses fixed.  Halving the bracket down to eps/L = 1e-7 as
@@ -1598,33 +1501,23 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
         }
         t_prev = t_mid; f_prev = f; have_prev = true; last_side = side;
         t_mid = t_next;
-      } else if (lo_tight && hi_tight) {
-        t_mid = (t_lo + t_hi) * 0.5f;
-      } else if (dp < 0.f) {
-        t_mid = fminf(t_lo + step, t_hi);
-        step *= 2.f;
-      } else {
-        t_mid = fmaxf(t_hi - step, t_lo);
-        step *= 2.f;
       }
     }
-    // (index hand-off: the 16-bit permutation takes the first half of the target row, the cut its last word; m >= 2)
-    if (G.idx_handoff) { if (tid == 0) G.cut_scratch_t[(long)s * m + (m - 1)] = t_mid; }
-    else if (G.cut_scratch && tid == 0) G.cut_scratch[(long)s * G.cut_stride] = t_mid;
+    if (G.cut_scratch && tid == 0) G.cut_scratch[(long)s * G.cut_stride] = t_mid;   // training: the gradient launch reads it
   }
 
   float cost;
   if constexpr (GRAD) {
     // Cost and its gradient at the cut: every atom's coefficient by its owner, once (walk_source_atoms)
-    Rotated<EPT, UNIFORM> R;
+    Rotated<EPT> R;
     R.set(T, t_mid, lane);
 #ifndef SHW_DBG_WALK
 #define SHW_DBG_WALK 0      // developer timing experiments only (wrong gradients): 1 = no target walk, 2 = no walk at all
 #endif
     float part = 0.f;
-    if (SHW_DBG_WALK < 2) part = walk_source_atoms<EPT, PMODE, UNIFORM, W>(S, R, tid, A.p, A.p_int, gs);
+    if (SHW_DBG_WALK < 2) part = walk_source_atoms<EPT, PMODE, W>(S, R, tid, A.p, A.p_int, gs);
     float sums[1] = {wave_sum_uniform(part, lane)};
-    if (SHW_DBG_WALK < 1) walk_target_atoms<EPT, PMODE, UNIFORM, W>(S, R, tid, A.p, A.p_int, gt, shared + 2);
+    if (SHW_DBG_WALK < 1) walk_target_atoms<EPT, PMODE, W>(S, R, tid, A.p, A.p_int, gt, shared + 2);
     team.sum(sums, lane);                                    // (W > 1: also the barrier that publishes gs, gt, tail)
     cost = sums[0];
     if constexpr (W == 1) __builtin_amdgcn_wave_barrier();
@@ -1656,7 +1549,7 @@ __global__ __launch_bounds__(64 * W, W > 1 ? (UNIFORM ? SHW_GENERAL_MINW_UNIFORM
       if (i < m) ct[i] = by_index_t[i];
     }
   } else {
-    cost = cut_cost<EPT, PMODE, UNIFORM, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team);
+    cost = cut_cost<EPT, PMODE, W>(S, T, t_mid, lane, tid, A.p, A.p_int, team);
   }
   if (tid == 0) {
     A.slice_cost[s] = cost;
@@ -1699,7 +1592,7 @@ __global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
   int sidx[EPT], tidx[EPT];
   float mean_s_unused = 0.f, mean_t_unused = 0.f;
   prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, scratch, sidx, tidx, mean_s_unused, mean_t_unused);
-  Side<EPT> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
+  Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
 
   float lo_lev = __builtin_inff(), hi_lev = -__builtin_inff(), total = 0.f;
   constexpr int NA = EPT < 4 ? EPT : 4;                      // atoms searched together (see lower_bounds2)
@@ -1805,21 +1698,21 @@ __global__ __launch_bounds__(64) void ssw_general_p1_kernel(GeneralArgs G) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// p == 1 with weights, >= 8 atoms per lane (round 2): the same formula as ssw_general_p1_kernel with
+// p == 1 with weights, >= 8 atoms per lane: the same formula as ssw_general_p1_kernel with
 //   * the two cross searches (target values below a source atom, source values not above a target atom) done by
-//     walking (walk_window: the lane's atoms ascend, so do their ranks in the other cloud's values);
-//   * levels and gaps of all 2 EPT atoms of the lane in REGISTERS: the median bisection reads no LDS (it was
-//     4 LDS reads per atom pair per step, ~40 steps per slice);
-//   * 6 rows of LDS instead of 8 (the two staging rows serve the source first, then the target): 3 slices per CU
-//     instead of 2;
+//     walking (walk_window: the lane's atoms ascend, so do their ranks in the other cloud's values; round 2);
+//   * levels and gaps in REGISTERS: the median bisection reads no LDS;
+//   * TWO waves per slice (round 3): wave 0 owns the source cloud, wave 1 the target -- its sort (at the same time as the
+//     other's), the levels and gaps of its atoms (one walk each, at the same time, straight into registers: the loop over a
+//     lane's atoms is unrolled), its share of every masked sum of the median bisection (added in wave order through LDS, one
+//     barrier per step) and its coefficient row.  Round 2's one-wave kernel kept the levels and gaps of BOTH clouds in
+//     registers (256 VGPRs + AGPRs, one wave per SIMD, three slices per CU): 3.3 -> 1.6 ms per loss, 3.8 -> 2.4 per
+//     training step at B = 64, n = m = 2048, L = 512; the loss-only form needs no staging rows (4 slices per CU);
 //   * coefficients un-permuted through LDS and stored coalesced.
 // ---------------------------------------------------------------------------------------------
-// levels and gaps of the atoms of one cloud (own) against the other (cross); SRC: own = source (rank = cross values
-// strictly below), else own = target (rank = cross values not above).  Rows lev_row / gap_row receive them at
-// [r][lane], dead atoms as (+inf, 0).  Returns the rank of the lane's first atom.
 template <int EPT, int C, bool SRC>
-__device__ __forceinline__ int p1_levels_walk(const Side<EPT>& O, const Side<EPT>& X, int lane, float* lev_row,
-                                              float* gap_row) {
+__device__ __forceinline__ int p1_levels_walk_regs(const Side<EPT>& O, const Side<EPT>& X, int lane, float (&lev_out)[EPT],
+                                                   float (&gap_out)[EPT]) {
   constexpr int P = EPT * kWave;
   constexpr int LEN = EPT / C;
   const int no = O.count, nx = X.count;
@@ -1834,7 +1727,7 @@ __device__ __forceinline__ int p1_levels_walk(const Side<EPT>& O, const Side<EPT
     ptr[c] = lower_bound_arr<EPT>(X.val, nx, prev[c]);
   }
   int first_rank = 0;
-#pragma nounroll
+#pragma unroll
   for (int i = 0; i < LEN; ++i) {
     float k[C], val[C], nxt_own[C];
     bool live[C];
@@ -1861,70 +1754,77 @@ __device__ __forceinline__ int p1_levels_walk(const Side<EPT>& O, const Side<EPT
       const float cross = rank < nx ? X.v(min(rank, P - 1)) : inf;
       const float nxt = fminf(nxt_own[c], cross);
       const float gap = (nxt == inf ? 1.f : nxt) - val[c];
-      lev_row[(c * LEN + i) * kWave + lane] = live[c] ? lev : inf;
-      gap_row[(c * LEN + i) * kWave + lane] = live[c] ? gap : 0.f;
+      lev_out[c * LEN + i] = live[c] ? lev : inf;
+      gap_out[c * LEN + i] = live[c] ? gap : 0.f;
     }
   }
   return first_rank;
 }
 
 template <int EPT, bool GRAD>
-__global__ __launch_bounds__(64) void ssw_general_p1_walk_kernel(GeneralArgs G) {
+__global__ __launch_bounds__(128, 2) void ssw_general_p1_walk2_kernel(GeneralArgs G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int ROW = EPT * kWave, EXT = kWalkExt * kWave;
   constexpr int C = 2;
   const SswArgs& A = G.base;
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* s_val = lds;                                        // each value row with its window rows
   float* t_val = s_val + ROW + EXT;
   float* s_cdf = t_val + ROW + EXT;
   float* t_cdf = s_cdf + ROW;
-  float* stage_a = t_cdf + ROW;                              // the sorts' scratch, then levels, then coefficients
-  float* stage_b = stage_a + ROW;                            // gaps, then coefficients
+  float* stage = t_cdf + ROW;                                // GRAD only: [2][ROW] coefficients by original index
+  float* team_mem = stage + (GRAD ? 2 * ROW : 0);
+  SliceTeam<2> team{team_mem, wave, 0};
+  float* shared = team_mem + 16;                             // [0..3] minima / maxima of the two waves
 
   const int s = xcd_contiguous_id(blockIdx.x, A.num_groups);
   if (s >= A.pairs * A.slices) return;
   const int n = A.n, m = A.m;
-  int sidx[EPT], tidx[EPT];
-  float mean_s_unused = 0.f, mean_t_unused = 0.f;
-  prepare_sides<EPT>(G, s, lane, s_val, s_cdf, t_val, t_cdf, stage_a, sidx, tidx, mean_s_unused, mean_t_unused,
-                     reinterpret_cast<unsigned*>(stage_b));
-  Side<EPT> S{s_val, s_cdf, n, 1.f / (float)n}, T{t_val, t_cdf, m, 1.f / (float)m};
-  fill_walk_ext<EPT>(s_val, lane);
-  fill_walk_ext<EPT>(t_val, lane);
-  __builtin_amdgcn_wave_barrier();
+  const bool src = wave == 0;                                // wave 0: the source cloud, wave 1: the target
+  int oidx[EPT];
+  {
+    float mean_unused;
+    float* dval = src ? s_val : t_val;
+    float* dcdf = src ? s_cdf : t_cdf;
+    // the wave's own rows serve as its sort scratch (see ssw_general_kernel)
+    prepare_one<EPT, false>(G, s, lane, src ? 1 : 0, dval, dcdf, dval, reinterpret_cast<unsigned*>(dcdf), oidx, mean_unused);
+    fill_walk_ext<EPT>(dval, lane);
+  }
+  __syncthreads();
+  Side<EPT> S{s_val, s_cdf, n}, T{t_val, t_cdf, m};
+  const Side<EPT>& O = src ? S : T;                          // own cloud
+  const int no = src ? n : m;
 
-  float lev_s[EPT], gap_s[EPT], lev_t[EPT], gap_t[EPT];
-  const int rank_s0 = p1_levels_walk<EPT, C, true>(S, T, lane, stage_a, stage_b);    // source atoms
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) { lev_s[r] = stage_a[r * kWave + lane]; gap_s[r] = stage_b[r * kWave + lane]; }
-  __builtin_amdgcn_wave_barrier();
-  const int rank_t0 = p1_levels_walk<EPT, C, false>(T, S, lane, stage_a, stage_b);   // target atoms
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) { lev_t[r] = stage_a[r * kWave + lane]; gap_t[r] = stage_b[r * kWave + lane]; }
+  float lev[EPT], gap[EPT];
+  int rank0;
+  if (src) rank0 = p1_levels_walk_regs<EPT, C, true>(S, T, lane, lev, gap);
+  else rank0 = p1_levels_walk_regs<EPT, C, false>(T, S, lane, lev, gap);
 
   const float inf = __builtin_inff();
   float lo_lev = inf, hi_lev = -inf, total = 0.f;
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
-    lo_lev = fminf(lo_lev, fminf(lev_s[r], lev_t[r]));
-    hi_lev = fmaxf(hi_lev, fmaxf(lev_s[r] < inf ? lev_s[r] : -inf, lev_t[r] < inf ? lev_t[r] : -inf));
-    total += gap_s[r] + gap_t[r];
+    lo_lev = fminf(lo_lev, lev[r]);
+    hi_lev = fmaxf(hi_lev, lev[r] < inf ? lev[r] : -inf);
+    total += gap[r];
   }
-  lo_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(-wave_max(-lo_lev, lane))));
-  hi_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(wave_max(hi_lev, lane))));
-  total = wave_sum_uniform(total, lane);
+  lo_lev = -wave_max(-lo_lev, lane);
+  hi_lev = wave_max(hi_lev, lane);
+  if (lane == 0) { shared[wave] = lo_lev; shared[2 + wave] = hi_lev; }
+  float sums[1] = {wave_sum_uniform(total, lane)};
+  team.sum(sums, lane);                                      // (its barrier also publishes the minima / maxima)
+  total = sums[0];
+  lo_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(fminf(shared[0], shared[1]))));
+  hi_lev = as_f(__builtin_amdgcn_readfirstlane(as_i(fmaxf(shared[2], shared[3]))));
 
-  auto weight_below = [&](float t) -> float {               // sum of gaps of atoms with level <= t
+  auto weight_below = [&](float t) -> float {               // sum of gaps of the slice's atoms with level <= t
     float w = 0.f;
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      w += (lev_s[r] <= t) ? gap_s[r] : 0.f;
-      w += (lev_t[r] <= t) ? gap_t[r] : 0.f;
-    }
-    return wave_sum_uniform(w, lane);
+    for (int r = 0; r < EPT; ++r) w += (lev[r] <= t) ? gap[r] : 0.f;
+    float sw[1] = {wave_sum_uniform(w, lane)};
+    team.sum(sw, lane);
+    return sw[0];
   };
   float med = lo_lev;
   if (total >= 0.5f) {
@@ -1936,51 +1836,42 @@ __global__ __launch_bounds__(64) void ssw_general_p1_walk_kernel(GeneralArgs G) 
     }
     float best = inf;                                        // smallest level above the bracket's lower end
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      best = (lev_s[r] > lo) ? fminf(best, lev_s[r]) : best;
-      best = (lev_t[r] > lo) ? fminf(best, lev_t[r]) : best;
-    }
-    med = as_f(__builtin_amdgcn_readfirstlane(as_i(-wave_max(-best, lane))));
+    for (int r = 0; r < EPT; ++r) best = (lev[r] > lo) ? fminf(best, lev[r]) : best;
+    best = -wave_max(-best, lane);
+    __syncthreads();                                         // (everyone has read the minima of the first exchange)
+    if (lane == 0) shared[wave] = best;
+    __syncthreads();
+    med = as_f(__builtin_amdgcn_readfirstlane(as_i(fminf(shared[0], shared[1]))));
   }
 
   float acc = 0.f;
-  if constexpr (GRAD) __builtin_amdgcn_wave_barrier();       // the staging rows have been read: coefficients by index
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int e = lane * EPT + r;
-    if (e < n) {
-      const float here = fabsf(lev_s[r] - med);
-      acc += gap_s[r] * here;
+    if (e < no) {
+      const float here = fabsf(lev[r] - med);
+      acc += gap[r] * here;
       if constexpr (GRAD) {
-        const float own = S.c(e) - (e > 0 ? S.c(e - 1) : 0.f);
-        const bool first = (e == 0) && (rank_s0 == 0);       // no target value below the first source atom
-        stage_a[sidx[r]] = (first ? 0.f : fabsf(lev_s[r] - own - med)) - here;
-      }
-    }
-    if (e < m) {
-      const float here = fabsf(lev_t[r] - med);
-      acc += gap_t[r] * here;
-      if constexpr (GRAD) {
-        const float own = T.c(e) - (e > 0 ? T.c(e - 1) : 0.f);
-        const bool first = (e == 0) && (rank_t0 == 0);       // no source value at or below the first target atom
-        stage_b[tidx[r]] = (first ? 0.f : fabsf(lev_t[r] + own - med)) - here;
+        const float own = O.c(e) - (e > 0 ? O.c(e - 1) : 0.f);
+        const bool first = (e == 0) && (rank0 == 0);         // no atom of the other cloud before (source) / at or before it
+        // source: the level before the atom's own weight is lev - own; target: lev + own
+        const float before = src ? lev[r] - own : lev[r] + own;
+        stage[(src ? 0 : ROW) + oidx[r]] = (first ? 0.f : fabsf(before - med)) - here;
       }
     }
   }
-  const float cost = wave_sum_uniform(acc, lane);
-  if (lane == 0) {
-    A.slice_cost[s] = cost;
+  float cs1[1] = {wave_sum_uniform(acc, lane)};
+  team.sum(cs1, lane);                                       // (GRAD: its barrier also publishes the staging rows)
+  if (threadIdx.x == 0) {
+    A.slice_cost[s] = cs1[0];
     if (G.slice_theta) G.slice_theta[s] = med;
   }
   if constexpr (GRAD) {
-    __builtin_amdgcn_wave_barrier();
     float* cs = A.coef_s + (long)s * n;
     float* ct = A.coef_t + (long)s * m;
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-      const int i = r * kWave + lane;
-      if (i < n) cs[i] = stage_a[i];
-      if (i < m) ct[i] = stage_b[i];
+    for (int i = (int)threadIdx.x; i < max(n, m); i += 128) {
+      if (i < n) cs[i] = stage[i];
+      if (i < m) ct[i] = stage[ROW + i];
     }
   }
 }
@@ -1995,10 +1886,10 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
   const dim3 grid((unsigned)total), block(64);
   if (A.p == 1.f && !A.bisect_p1) {
     if constexpr (EPT >= 8) {
-      const size_t lds1 = ((size_t)6 * EPT * kWave + 2 * kWalkExt * kWave) * sizeof(float);
-      if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
-      if (grad) hipLaunchKernelGGL((ssw_general_p1_walk_kernel<EPT, true>), grid, block, lds1, stream, G);
-      else hipLaunchKernelGGL((ssw_general_p1_walk_kernel<EPT, false>), grid, block, lds1, stream, G);
+      const size_t lds2 = ((size_t)(grad ? 6 : 4) * EPT * kWave + 2 * kWalkExt * kWave + kTeamFloats) * sizeof(float);
+      if (lds2 > 160 * 1024) return (int)hipErrorInvalidValue;
+      if (grad) hipLaunchKernelGGL((ssw_general_p1_walk2_kernel<EPT, true>), grid, dim3(128), lds2, stream, G);
+      else hipLaunchKernelGGL((ssw_general_p1_walk2_kernel<EPT, false>), grid, dim3(128), lds2, stream, G);
     } else {
       const size_t lds1 = (size_t)8 * EPT * kWave * sizeof(float);
       if (grad) hipLaunchKernelGGL((ssw_general_p1_kernel<EPT, true>), grid, block, lds1, stream, G);
@@ -2012,8 +1903,7 @@ static int launch_general(GeneralArgs& G, hipStream_t stream) {
 #define SHW_LAUNCH_GENERAL(PM, GR, ARGS)                                                                       \
   do {                                                                                                         \
     const size_t lds_ = ((size_t)((uniform ? 2 : 4) + ((GR) ? 2 : 0)) * EPT * kWave + kTeamFloats +            \
-                         (uniform ? general_counter_floats<EPT, true, W>() : general_ext_floats<EPT, false>())) *  \
-                        sizeof(float) + SHW_DBG_EXTRA_LDS;                                                      \
+                         (uniform ? 0 : general_ext_floats<EPT>())) * sizeof(float) + SHW_DBG_EXTRA_LDS; \
     if (uniform) hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, true, W>), grid, wblock, lds_, stream, ARGS); \
     else hipLaunchKernelGGL((ssw_general_kernel<EPT, PM, GR, false, W>), grid, wblock, lds_, stream, ARGS);        \
   } while (0)
@@ -2051,17 +1941,12 @@ static int gcd_general(int a, int b) {
 
 int dispatch_general(SswArgs& A, const float* wu, const float* wv, long wu_pair_stride, long wv_pair_stride,
                      float* slice_theta, hipStream_t stream) {
-  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0.f, 0, 0, 0, nullptr, nullptr, 0, 0, 0};
-  if (wu == nullptr && wv == nullptr) {                      // kinks sit on the grid of 1 / lcm(n, m)
-    const double lcm = (double)A.n / (double)gcd_general(A.n, A.m) * (double)A.m;
-    G.lcm = (int)lcm;                                        // n, m <= 4096: < 2^24 -- the integer grid of the solve
+  GeneralArgs G{A, wu, wv, wu_pair_stride, wv_pair_stride, slice_theta, 0.f, 0.f, 0, 0, 0, nullptr, nullptr, 0, 0, 0};
+  if (wu == nullptr && wv == nullptr) {                      // no weights: the integer grid of lcm(n, m)
+    const long lcm = (long)A.n / gcd_general(A.n, A.m) * (long)A.m;
+    G.lcm = (int)lcm;                                        // n, m <= 4096: < 2^24
     G.lcm_a = G.lcm / A.n;
     G.lcm_b = G.lcm / A.m;
-    G.grid = lcm <= 4.0e6 ? (float)lcm : 0.f;                // (finer than 2.5e-7: leave it to the tangent step)
-    G.first_step = (float)(1.0 / lcm);
-    G.min_width = (float)(0.5 / lcm);
-    if (G.min_width < 1e-7f) G.min_width = 1e-7f;            // never tighter than the reference's eps / L
-    if (G.first_step < 1e-7f) G.first_step = 1e-7f;
   } else {
     G.first_step = 0.25f / (float)(A.n + A.m);
     G.min_width = 1e-7f;                                     // eps / L, :189
