@@ -31,8 +31,10 @@ template <int EPT, int W, int KPB = SHW_COOP_KEYS_PER_BIN>
 struct Coop {
   static constexpr int NCOL = 64 * W;                       // lanes per slice
   static constexpr int CAP = EPT * NCOL;                    // keys per slice (padded)
-  static constexpr int NB = SHW_COOP_BINS_PER_KEY * CAP / KPB;    // bins
-  static constexpr int BPL = NB / NCOL;                     // bins per lane in the scan
+  // bins per lane in the scan: EPT / KPB for the power-of-two classes; rounded DOWN to a multiple of four otherwise
+  // (128-bit accesses; 20 keys per lane: 8 bins per lane, 2.5 keys per bin -- never more counters than half a row)
+  static constexpr int BPL = is_pow2(EPT) ? SHW_COOP_BINS_PER_KEY * EPT / KPB : (SHW_COOP_BINS_PER_KEY * EPT / KPB) / 4 * 4;
+  static constexpr int NB = BPL * NCOL;                     // bins
   static constexpr int RED = 12 * W + 16;                   // ints / floats of cross-wave scratch
   static constexpr int LDS_FLOATS = NB + CAP + RED;
   static_assert(EPT % 4 == 0 && BPL % 4 == 0, "128-bit LDS accesses need multiples of four");
@@ -74,6 +76,32 @@ __device__ __forceinline__ void coop_bitonic(float (&key)[EPT], float* buf, int 
       coop_exchange<EPT, W>(key, buf, wave, lane, wave ^ (1 << t), false, (wave & (1 << t)) != 0);
     xlane_stages<F32Keys, EPT, 32>(key, lane);
     lane_stages<F32Keys, EPT, EPT / 2>(key);
+  }
+}
+
+// The fallback of a class that is not a power of two (long runs: clustered data, duplicates): a bitonic network on the
+// keys where they sit in LDS.  `a` holds `cap` keys in plain order; the network runs over next_pow2(cap) positions whose
+// tail is virtual +inf -- in the flip form of the network every comparator sends the larger key to the higher index, so
+// the virtual keys never move and are never touched.  One barrier per stage (~80 of them at 4096 slots): slow, rare.
+template <class T>
+__device__ __forceinline__ void lds_bitonic_stage(T* a, int cap, int tid, int nthr, int mask) {
+  for (int i = tid; i < cap; i += nthr) {
+    const int j = i ^ mask;
+    if (j > i && j < cap) {                                  // (j >= cap: the partner is a virtual +inf)
+      const T x = a[i], y = a[j];
+      if (y < x) { a[i] = y; a[j] = x; }
+    }
+  }
+  __syncthreads();
+}
+
+template <class T>
+__device__ __forceinline__ void lds_bitonic_sort(T* a, int cap, int tid, int nthr) {
+  int P = 1;
+  while (P < cap) P <<= 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    lds_bitonic_stage(a, cap, tid, nthr, k - 1);             // merge of blocks of k: i against its mirror image
+    for (int s = k >> 2; s >= 1; s >>= 1) lds_bitonic_stage(a, cap, tid, nthr, s);
   }
 }
 
@@ -157,7 +185,17 @@ __device__ __forceinline__ void coop_sort(float (&key)[EPT], int wave, int lane,
   if (g > SHW_COOP_MAX_RUN) {
     // long runs (clustered data, duplicates): the network sorts it; counters re-zeroed for the next sort
     coop_zero_counters<EPT, W>(cnt, gl);
-    coop_bitonic<EPT, W>(key, buf, wave, lane);
+    if constexpr (is_pow2(EPT)) {
+      coop_bitonic<EPT, W>(key, buf, wave, lane);
+    } else {
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) buf[r * C::NCOL + gl] = key[r];
+      __syncthreads();
+      lds_bitonic_sort<float>(buf, C::CAP, gl, C::NCOL);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) key[r] = buf[gl * EPT + r];
+      __syncthreads();
+    }
     return;
   }
   // ---- 3. scatter ----------------------------------------------------------------------------------------------

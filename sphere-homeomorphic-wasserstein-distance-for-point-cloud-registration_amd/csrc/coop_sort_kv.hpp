@@ -133,7 +133,17 @@ __device__ __forceinline__ void coop_sort_kv(item_t (&it)[EPT], int wave, int la
   if (g > SHW_COOP_MAX_RUN) {
     // long runs (clustered data, duplicates): the network sorts it; counters re-zeroed for the next sort
     coop_zero_counters<EPT, W, KPB>(cnt, gl);
-    coop_bitonic_kv<EPT, W>(it, buf, wave, lane);
+    if constexpr (is_pow2(EPT)) {
+      coop_bitonic_kv<EPT, W>(it, buf, wave, lane);
+    } else {                                                 // (see lds_bitonic_sort; items are unique: plain <)
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) buf[r * C::NCOL + gl] = it[r];
+      __syncthreads();
+      lds_bitonic_sort<item_t>(buf, C::CAP, gl, C::NCOL);
+#pragma unroll
+      for (int r = 0; r < EPT; ++r) it[r] = buf[gl * EPT + r];
+      __syncthreads();
+    }
     return;
   }
   // ---- 3. scatter ----------------------------------------------------------------------------------------------

@@ -134,15 +134,17 @@ static int launch_forward_coop(SswArgs& A, hipStream_t stream) {
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  const bool full = (A.n == C::CAP) && (A.m == C::CAP);
+  const bool full = is_pow2(EPT) && (A.n == C::CAP) && (A.m == C::CAP);
   const dim3 grid((unsigned)total), block(W * 64);
-  if (A.p_int == 2) {
-    if (full) hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 2, true>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 2, false>), grid, block, lds, stream, A);
-  } else {
-    if (full) hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 0, true>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 0, false>), grid, block, lds, stream, A);
+  if constexpr (is_pow2(EPT)) {                            // (the mask-free forms: power-of-two classes only)
+    if (full) {
+      if (A.p_int == 2) hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 2, true>), grid, block, lds, stream, A);
+      else hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 0, true>), grid, block, lds, stream, A);
+      return (int)hipGetLastError();
+    }
   }
+  if (A.p_int == 2) hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 2, false>), grid, block, lds, stream, A);
+  else hipLaunchKernelGGL((ssw_forward_coop_kernel<EPT, W, 0, false>), grid, block, lds, stream, A);
   return (int)hipGetLastError();
 }
 
@@ -150,17 +152,25 @@ static int launch_forward_coop(SswArgs& A, hipStream_t stream) {
 #define SHW_COOP_EPT 32     // keys per lane (measured at 2048 points: 32 / W=1: 0.267 ms, 16 / W=2: 0.288, 8 / W=4: 0.292)
 #endif
 
-// padded point count -> cooperative kernel (SHW_COOP_EPT keys per lane, W = padded / (64 * EPT) waves per slice)
+// point count -> cooperative kernel: W = 2 waves per slice up to 4096 points, 4 up to 8192, and 20 / 24 / 32 keys per
+// lane (round 3: a cloud of 3000 points pays for 3072 slots, not 4096; SHW_KPL_CLASSES=0 keeps 32)
 int dispatch_forward_coop(SswArgs& A, hipStream_t stream) {
   constexpr int E = SHW_COOP_EPT;
-  const int padded = next_pow2(A.n > A.m ? A.n : A.m);
-  switch (padded / (64 * E)) {
+  const int big = A.n > A.m ? A.n : A.m;
+  const int padded = next_pow2(big);
+  const int W = padded / (64 * E);
+  const int kpl = (W >= 2) ? coop_kpl_for(big, W, false) : E;
+  switch (W * 100 + kpl) {
 #ifdef SHW_DEV_ONLY_EPT      // developer switch: only the 2048-point class
-    case 2048 / (64 * E): return launch_forward_coop<E, 2048 / (64 * E)>(A, stream);
+    case (2048 / (64 * E)) * 100 + E: return launch_forward_coop<E, 2048 / (64 * E)>(A, stream);
 #else
-    case 1: return launch_forward_coop<E, 1>(A, stream);
-    case 2: return launch_forward_coop<E, 2>(A, stream);
-    case 4: return launch_forward_coop<E, 4>(A, stream);
+    case 100 + E: return launch_forward_coop<E, 1>(A, stream);
+    case 220: return launch_forward_coop<20, 2>(A, stream);
+    case 224: return launch_forward_coop<24, 2>(A, stream);
+    case 232: return launch_forward_coop<32, 2>(A, stream);
+    case 420: return launch_forward_coop<20, 4>(A, stream);
+    case 424: return launch_forward_coop<24, 4>(A, stream);
+    case 432: return launch_forward_coop<32, 4>(A, stream);
 #endif
     default: return (int)hipErrorInvalidValue;
   }

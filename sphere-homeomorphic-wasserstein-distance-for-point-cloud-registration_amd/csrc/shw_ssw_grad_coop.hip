@@ -31,7 +31,6 @@ __global__ __launch_bounds__(W * 64, W == 2 ? SHW_GRADCOOP_MINW : 1) void ssw_fo
   constexpr int KPB = SHW_GRADCOOP_KPB;
   typedef Coop<EPT, W, KPB> C;
   typedef ExtRows<EPT, C::NCOL> X;
-  constexpr int LOG = __builtin_ctz(EPT);
   static_assert(C::NB * 2 <= C::CAP, "counters take at most half a row: the index row takes the other half");
   static_assert(X::FLOATS <= 2 * C::CAP, "extended rows fit the item buffer");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -160,13 +159,13 @@ __global__ __launch_bounds__(W * 64, W == 2 ? SHW_GRADCOOP_MINW : 1) void ssw_fo
     const int q = min(e, n - 1) + k;                            // in [-n, 2n): one turn at most
     const int turn = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
     const int qq = q - turn * n;
-    const int tslot = (qq & (EPT - 1)) * C::NCOL + (qq >> LOG);
+    const int tslot = lds_slot<EPT, C::NCOL>(qq);
     float tv;
     if constexpr (FULL) {
       tv = rows[tslot] + (float)turn;
     } else {
       const int E = min(e, n - 1) + (k - kc) + X::M;            // the rows hold the turns already
-      tv = rows[(E & (EPT - 1)) * X::RS + (E >> LOG)];
+      tv = rows[emod<EPT>(E) * X::RS + ediv<EPT>(E)];
     }
     const float d = u[r] - tv;
     u[r] = dpow_abs<PMODE>(d, A.p, A.p_int) * inv_n;
@@ -197,7 +196,7 @@ static int launch_forward_grad_coop(SswArgs& A, hipStream_t stream) {
   if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
   A.num_groups = (int)total;
   const size_t lds = (size_t)(3 * C::CAP + C::RED) * sizeof(float);
-  const bool full = (A.n == C::CAP) && (A.m == C::CAP);
+  const bool full = is_pow2(EPT) && (A.n == C::CAP) && (A.m == C::CAP);
   const dim3 grid((unsigned)total), block(W * 64);
 #define SHW_LAUNCH_GRAD_COOP(PM, FL)                                                                              \
   do {                                                                                                            \
@@ -213,23 +212,29 @@ static int launch_forward_grad_coop(SswArgs& A, hipStream_t stream) {
     }                                                                                                             \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, A);                                                        \
   } while (0)
-  if (A.p_int == 2) {
-    if (full) SHW_LAUNCH_GRAD_COOP(2, true); else SHW_LAUNCH_GRAD_COOP(2, false);
-  } else {
-    if (full) SHW_LAUNCH_GRAD_COOP(0, true); else SHW_LAUNCH_GRAD_COOP(0, false);
+  if constexpr (is_pow2(EPT)) {                            // (the mask-free forms: power-of-two classes only)
+    if (full) {
+      if (A.p_int == 2) SHW_LAUNCH_GRAD_COOP(2, true); else SHW_LAUNCH_GRAD_COOP(0, true);
+      return (int)hipGetLastError();
+    }
   }
+  if (A.p_int == 2) SHW_LAUNCH_GRAD_COOP(2, false); else SHW_LAUNCH_GRAD_COOP(0, false);
 #undef SHW_LAUNCH_GRAD_COOP
   return (int)hipGetLastError();
 }
 
-// padded point count 4096 / 8192 -> W = 2 / 4 waves of 32 atoms per lane
+// 2049..4096 points: W = 2 waves per slice, 4097..8192: W = 4; 20 / 24 / 32 atoms per lane (round 3: 3000 points pay
+// for 3072 slots, 5000 for 5120)
 int dispatch_forward_grad_coop(SswArgs& A, hipStream_t stream) {
   if (A.n != A.m) return (int)hipErrorInvalidValue;
-  const int padded = next_pow2(A.n);
-  switch (padded / 2048) {
+  const int W = next_pow2(A.n) / 2048;
+  switch (W * 100 + coop_kpl_for(A.n, W, true)) {
 #ifndef SHW_DEV_ONLY_EPT
-    case 2: return launch_forward_grad_coop<32, 2>(A, stream);
-    case 4: return launch_forward_grad_coop<32, 4>(A, stream);
+    case 220: return launch_forward_grad_coop<20, 2>(A, stream);
+    case 224: return launch_forward_grad_coop<24, 2>(A, stream);
+    case 232: return launch_forward_grad_coop<32, 2>(A, stream);
+    case 420: return launch_forward_grad_coop<20, 4>(A, stream);
+    case 432: return launch_forward_grad_coop<32, 4>(A, stream);
 #endif
     default: return (int)hipErrorInvalidValue;
   }

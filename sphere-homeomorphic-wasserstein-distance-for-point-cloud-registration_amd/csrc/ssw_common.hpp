@@ -744,6 +744,18 @@ inline int kpl_for(int n, int m) {
   return e;
 }
 
+// keys per lane of the cooperative kernels above 2048 points (W = 2 or 4 waves per slice): 20, 24 or 32.  Measured per
+// pair at B N ~ 131 k, L = 512 (profiles/r03_size_sweep.txt): 28 keys per lane is never faster than 32 (the partially
+// filled 32 class costs the same), nor is 24 at W = 4 in training; 20 and 24 pay (N = 3000: training 1.40 -> 0.83 ms,
+// N = 5000: 1.88 -> 0.89).
+inline int coop_kpl_for(int points, int W, bool training) {
+  static const bool fine = [] { const char* v = getenv("SHW_KPL_CLASSES"); return !(v && v[0] == '0'); }();
+  if (!fine) return 32;
+  if (20 * 64 * W >= points) return 20;
+  if (24 * 64 * W >= points && !(training && W == 4)) return 24;
+  return 32;
+}
+
 // dispatchers, one per translation unit (SswArgs validated by the C entry points in shw_capi.hip)
 int dispatch_forward(SswArgs& A, hipStream_t stream);        // shw_ssw_fwd.hip   p != 1, loss only
 int dispatch_forward_grad(SswArgs& A, hipStream_t stream);   // shw_ssw_grad.hip  p != 1, loss + coefficients
