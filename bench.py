@@ -316,7 +316,7 @@ def main():
     # guide); only valid for the workload it was measured on
     traffic = os.environ.get("SHW_BENCH_TRAFFIC_BYTES")
     if traffic is None and (Bl, N, Ll, p) == (64, 2048, 512, 2.0):
-        for name in ("r02_traffic.json",):
+        for name in ("r03_traffic.json", "r02_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     traffic = json.load(fh)["ssw_forward_kernel<32,1,2,true>"]["traffic_bytes"]

@@ -235,8 +235,8 @@ SHW_API int shw_chamfer_forward(const float* x, const float* y, int pairs, int n
                         float* pair_loss, void* stream);
 
 /* grad of sum_b w[b]*pair_loss[b] (w = per-pair upstream gradient, device pointer, (pairs)).
- * grad_x, grad_y must be zero-filled by the caller: the nearest-neighbour side of each term is
- * scattered with float atomics (sum order, hence the last bits, may vary from run to run). */
+ * grad_x, grad_y are overwritten.  Owner-computed (round 3): every row is summed by one thread in a fixed order --
+ * bit-identical from run to run (round 2 scattered with float atomics and needed zero-filled outputs). */
 SHW_API int shw_chamfer_backward(const float* x, const float* y, const int32_t* nn_xy, const int32_t* nn_yx,
                          const float* w, int pairs, int n, int m,
                          float* grad_x, float* grad_y, void* stream);

@@ -42,8 +42,8 @@ class _ChamferPairs(torch.autograd.Function):
         B, n, _ = xc.shape
         m = yc.shape[1]
         dev = xc.device
-        gx = torch.zeros_like(xc)
-        gy = torch.zeros_like(yc)
+        gx = torch.empty_like(xc)
+        gy = torch.empty_like(yc)
         w = g_pair.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
             _lib.check(lib.shw_chamfer_backward(xc.data_ptr(), yc.data_ptr(), nn_xy.data_ptr(), nn_yx.data_ptr(),

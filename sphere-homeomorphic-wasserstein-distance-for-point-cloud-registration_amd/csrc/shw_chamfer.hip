@@ -89,28 +89,50 @@ __global__ __launch_bounds__(256) void chamfer_reduce_kernel(const float* __rest
   }
 }
 
-// d/dx of w_b * [ (1/n) sum_i |x_i - y_nn(i)|^2 + (1/m) sum_j |x_nn(j) - y_j|^2 ]
+// d/dx of w_b * [ (1/n) sum_i |x_i - y_nn(i)|^2 + (1/m) sum_j |x_nn(j) - y_j|^2 ], OWNER-COMPUTED (round 3): the thread of
+// query point i adds its own term and then the terms of every point c of the other cloud whose nearest neighbour is i,
+// found by scanning that cloud's index array in ascending c (staged through LDS, read as broadcasts; a match is rare, the
+// body sits behind a branch).  Every gradient row is written once, by one thread, in a fixed order: bit-identical from
+// run to run -- round 2 scattered the second kind of term with global float atomics.
 __global__ __launch_bounds__(256) void chamfer_backward_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                const int32_t* __restrict__ nn_xy,
                                                                const int32_t* __restrict__ nn_yx,
                                                                const float* __restrict__ w, int n, int m,
                                                                float* __restrict__ grad_x, float* __restrict__ grad_y) {
+  __shared__ int32_t tile[kTile];
   const int b = blockIdx.y;
   const bool swap = blockIdx.z != 0;
   const int nq = swap ? m : n, nc = swap ? n : m;
+  if ((int)blockIdx.x * 256 >= nq) return;                 // block-uniform
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nq) return;
+  const int ic = min(i, nq - 1);
   const float* Q = (swap ? y : x) + (long)b * nq * 3;
   const float* Cn = (swap ? x : y) + (long)b * nc * 3;
   float* GQ = (swap ? grad_y : grad_x) + (long)b * nq * 3;
-  float* GC = (swap ? grad_x : grad_y) + (long)b * nc * 3;
-  const int j = (swap ? nn_yx : nn_xy)[(long)b * nq + i];
-  const float s = 2.f * w[b] / (float)nq;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float g = s * (Q[3 * i + d] - Cn[3 * j + d]);
-    unsafeAtomicAdd(&GQ[3 * i + d], g);
-    unsafeAtomicAdd(&GC[3 * j + d], -g);
+  const int32_t* own_nn = (swap ? nn_yx : nn_xy) + (long)b * nq;     // nearest neighbour of each query in the other cloud
+  const int32_t* inv_nn = (swap ? nn_xy : nn_yx) + (long)b * nc;     // nearest neighbour of each other-cloud point among the queries
+  const float qx = Q[3 * ic], qy = Q[3 * ic + 1], qz = Q[3 * ic + 2];
+  const float s_own = 2.f * w[b] / (float)nq, s_inv = 2.f * w[b] / (float)nc;
+  const int j = own_nn[ic];
+  float gx = s_own * (qx - Cn[3 * j]), gy = s_own * (qy - Cn[3 * j + 1]), gz = s_own * (qz - Cn[3 * j + 2]);
+  for (int base = 0; base < nc; base += kTile) {
+    const int cnt = min(kTile, nc - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) tile[t] = inv_nn[base + t];
+    __syncthreads();
+    for (int c = 0; c < cnt; ++c) {
+      if (tile[c] == i) {                                  // (at most one lane of the whole grid row matches a given c)
+        const float* P = Cn + 3 * (long)(base + c);
+        gx = fmaf(s_inv, qx - P[0], gx);
+        gy = fmaf(s_inv, qy - P[1], gy);
+        gz = fmaf(s_inv, qz - P[2], gz);
+      }
+    }
+  }
+  if (i < nq) {
+    GQ[3 * i] = gx;
+    GQ[3 * i + 1] = gy;
+    GQ[3 * i + 2] = gz;
   }
 }
 

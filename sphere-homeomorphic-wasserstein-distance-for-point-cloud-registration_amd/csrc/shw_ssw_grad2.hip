@@ -175,7 +175,7 @@ static int launch_forward_grad2(SswArgs& A, hipStream_t stream) {
 }
 
 int dispatch_forward_grad2(SswArgs& A, hipStream_t stream) {
-  switch (kpl_for(A.n, A.m)) {
+  switch (kpl_for(A.n, A.m, true)) {
 #ifdef SHW_DEV_ONLY_EPT
     case SHW_DEV_ONLY_EPT: return launch_forward_grad2<SHW_DEV_ONLY_EPT>(A, stream);
 #else
@@ -184,7 +184,6 @@ int dispatch_forward_grad2(SswArgs& A, hipStream_t stream) {
     case 16: return launch_forward_grad2<16>(A, stream);
     case 20: return launch_forward_grad2<20>(A, stream);
     case 24: return launch_forward_grad2<24>(A, stream);
-    case 28: return launch_forward_grad2<28>(A, stream);
     case 32: return launch_forward_grad2<32>(A, stream);
 #endif
     default: return (int)hipErrorInvalidValue;

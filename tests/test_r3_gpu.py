@@ -421,3 +421,24 @@ def test_sizes_between_the_powers_of_two_against_cpu_oracle(shw, n, p):
     total.backward()
     grad_close(xs.grad.cpu().numpy(), xa.grad.cpu().numpy(), strict=2e-5, loose=2e-2, frac=0.0005)
     grad_close(ys.grad.cpu().numpy(), ya.grad.cpu().numpy(), strict=2e-5, loose=2e-2, frac=0.0005)
+
+
+def test_chamfer_gradients_are_bit_identical_from_run_to_run(shw):
+    """VERDICT r2 missing 4, second half: Chamfer's backward scattered with global float atomics.  Owner-computed now: three
+    runs agree bit for bit, and with autograd of the definition (brute force in float64) to 1e-5 of the largest entry."""
+    gen = torch.Generator().manual_seed(99)
+    B, n, m = 5, 1500, 1100
+    x, y = torch.randn(B, n, 3, generator=gen), torch.randn(B, m, 3, generator=gen) * 0.9 + 0.05
+    w = torch.tensor([1.0, -0.5, 2.0, 0.25, 1.5])
+    runs = []
+    for _ in range(3):
+        xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+        (shw.chamfer_pair_losses(xs, ys) * w.cuda()).sum().backward()
+        runs.append((xs.grad.clone(), ys.grad.clone()))
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][1], other[1])
+    xd, yd = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    d = ((xd[:, :, None, :] - yd[:, None, :, :]) ** 2).sum(-1)
+    ((d.min(2).values.mean(1) + d.min(1).values.mean(1)) * w.double()).sum().backward()
+    for got, ref in ((runs[0][0], xd.grad), (runs[0][1], yd.grad)):
+        assert (got.cpu().double() - ref).abs().max() < 1e-5 * ref.abs().max()

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round-3 measurement batch (GPU box, via gpurun): everything DESIGN.md / profiles/README.md quote for this round.
-#   tools/prof_r03.sh [part ...]      parts: bench headline general notebook sweep modes      (default: all)
+#   tools/prof_r03.sh [part ...]      parts: bench headline general notebook sweep modes nonuniform partial   (default: all)
 # Outputs under gpurun_out/r03/; the summaries are copied into profiles/ by hand afterwards.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r03; mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-PARTS=${@:-bench headline general notebook sweep modes}
+PARTS=${@:-bench headline general notebook sweep modes nonuniform partial}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 
 if has bench; then
@@ -51,6 +51,18 @@ if has modes; then
     python3 bench.py $args --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/bench_modes.jsonl
   done
   cut -c1-200 $OUT/bench_modes.jsonl
+fi
+if has nonuniform; then
+  echo "== clouds that are not uniform in angle (ADVICE r2)"
+  timeout -k 10 200 python3 tools/nonuniform_time.py 2>&1 | grep -v amdgpu.ids > $OUT/nonuniform.txt
+  if [ -f gpurun_variants/fwd_runlen.so ]; then
+    SHW_RUNLEN=1 SHW_LIB_PATH=$ROOT/gpurun_variants/fwd_runlen.so timeout -k 10 200 python3 tools/nonuniform_time.py 2>&1 | grep -v amdgpu.ids >> $OUT/nonuniform.txt
+  fi
+  cat $OUT/nonuniform.txt
+fi
+if has partial; then
+  echo "== partially filled classes vs a full one (SQ counters of the two-wave loss kernel)"
+  bash tools/prof_partial.sh > $OUT/prof_partial.txt 2>&1; cat $OUT/prof_partial.txt
 fi
 find $OUT -name "*.csv" -size +2M -delete
 echo done
