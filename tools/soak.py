@@ -46,7 +46,10 @@ def main(budget=None):
     gen = torch.Generator().manual_seed(2025)
     t_end = time.time() + budget
     slices_done, trips, bad = 0, 0, 0
-    sizes = [(64, 64), (256, 256), (1000, 1000), (1024, 1024), (2048, 2048), (2000, 2000), (4096, 4096), (100, 100), (1, 1), (63, 63), (65, 65), (8192, 8192), (3000, 3000), (130, 130)]
+    # (round 3: 600 / 1200 / 1500 / 1700 and 2600 / 5000 / 6000 take the keys-per-lane classes of 12 / 20 / 24 / 28 and the
+    #  cooperative 20 / 24 classes)
+    sizes = [(64, 64), (256, 256), (1000, 1000), (1024, 1024), (2048, 2048), (2000, 2000), (4096, 4096), (100, 100), (1, 1), (63, 63), (65, 65), (8192, 8192), (3000, 3000), (130, 130),
+             (600, 600), (1200, 1200), (1500, 1500), (1700, 1700), (2600, 2600), (5000, 5000), (6000, 6000)]
     kinds = ["sphere", "registration", "centred", "grid", "gauss"]
     while time.time() < t_end:
         n, m = sizes[trips % len(sizes)]
@@ -171,7 +174,30 @@ def main(budget=None):
             for name, t in (("weighted cost", c_a), ("weighted p1", c_c), ("weighted gx", xs.grad), ("weighted gy", y2.grad)):
                 if not bool(torch.isfinite(t).all()):
                     problems.append(f"non-finite {name}")
+        if trips % 6 == 2 and n >= 2:
+            # round 3: a launch with few slices takes the latency kernels (W waves per slice of 8 keys per lane from 513 points
+            # on): the first pair's first 48 slices alone must reproduce the big launch's costs, shifts and -- summed the same
+            # way -- nothing non-finite in the gradients
+            poison()
+            xa, ya = x[:1].clone().requires_grad_(True), y[:1].clone().requires_grad_(True)
+            pair_s, c_s, k_s = shw.ssw_pair_losses(xa, ya, U[:1, :48].contiguous(), 2, return_slices=True)
+            poison()
+            pair_s.sum().backward()
+            if not torch.allclose(c_s, c_g[:1, :48], rtol=3e-6, atol=1e-12):
+                problems.append(f"small grid vs throughput kernels: max rel {float(((c_s - c_g[:1, :48]).abs() / (c_g[:1, :48] + 1e-12)).max())}")
+            if float((k_s != k_g[:1, :48]).float().mean()) > 0.05:
+                problems.append("small grid vs throughput kernels: shifts differ")
+            if not (bool(torch.isfinite(xa.grad).all()) and bool(torch.isfinite(ya.grad).all())):
+                problems.append("small grid: non-finite gradient")
         if trips % 5 == 0:
+            poison()
+            xc1, yc1 = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+            shw.chamfer_pair_losses(xc1, yc1).sum().backward()
+            xc2, yc2 = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+            poison()
+            shw.chamfer_pair_losses(xc2, yc2).sum().backward()
+            if not (torch.equal(xc1.grad, xc2.grad) and torch.equal(yc1.grad, yc2.grad)):
+                problems.append("chamfer gradients differ between two runs")
             poison()
             cd = shw.chamfer_distance(xs, ys)
             cd0 = cd[0] if isinstance(cd, (tuple, list)) else cd
