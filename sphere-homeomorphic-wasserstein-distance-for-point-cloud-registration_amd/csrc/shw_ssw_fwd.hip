@@ -13,9 +13,6 @@
 #ifndef SHW_BINSORT_NB_PER_EPT
 #define SHW_BINSORT_NB_PER_EPT 32   // bins = this * keys-per-lane (32: two keys per bin on average)
 #endif
-#ifndef SHW_SOLVE5
-#define SHW_SOLVE5 1       // full classes: the shift solve on five-point windows (ssw_common.hpp, solve_shift5)
-#endif
 #ifndef SHW_FWD_WAVES
 #define SHW_FWD_WAVES 1    // wavefronts per workgroup of the one-wave-per-slice kernel
 #endif
@@ -113,11 +110,6 @@ __global__ __launch_bounds__(WAVES * 64, forward_min_waves(EPT, PMODE, FULL)) vo
   const int k = 0;
 #else
   int k;
-#if SHW_SOLVE5
-  if constexpr (FULL && EPT >= 8) {
-    k = solve_shift5<EPT, PMODE>(u, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
-  } else
-#endif
   if constexpr (FULL || !BINS) {
     k = solve_shift<EPT, PMODE, FULL>(u, vbuf, lane, A.n, sum_u, sum_v, A.p, A.p_int, best);
   } else {

@@ -310,96 +310,6 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
   return k;
 }
 
-// Five shifts at once: c(k-2) .. c(k+2) (sums, valid in every lane), n == 64*EPT as shift_costs3_full.  On independent
-// clouds the first guess k0 = round(sum u - sum v) is off by one or two more often than not (2.1 three-point evaluations
-// per slice, round 2): a five-point window around it holds the minimiser AND both its neighbours in most slices, for
-// 36 window fetches + 160 terms instead of 2.1 x (34 + 96).
-template <int EPT, int PMODE, int NCOL = 64>
-__device__ __forceinline__ void shift_costs5_full(const float (&u)[EPT], const float* vbuf, int lane, int k, float p,
-                                                  int p_int, float (&c)[5]) {
-  constexpr int LOG = __builtin_ctz(EPT);
-  const int base = k - 2;
-  const int kl = base & (EPT - 1);
-  const int kh = base >> LOG;                                   // floor division (arithmetic shift)
-  int addr[3];
-  float turn[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int col = lane + kh + q;
-    addr[q] = (col & (NCOL - 1)) << 2;
-    turn[q] = (float)(col >> __builtin_ctz(NCOL));
-  }
-  const char* rows = reinterpret_cast<const char*>(vbuf);
-  auto fetch = [&](int j) -> float {                            // j compile-time after unrolling; kl + j < 3 EPT
-    const int rj = kl + j;                                      // scalar
-    const int row = rj & (EPT - 1);
-    const bool carry = (j < EPT) ? (rj >= EPT) : (rj >= 2 * EPT);
-    const int a = (j < EPT) ? (carry ? addr[1] : addr[0]) : (carry ? addr[2] : addr[1]);
-    const float t = (j < EPT) ? (carry ? turn[1] : turn[0]) : (carry ? turn[2] : turn[1]);
-    return *reinterpret_cast<const float*>(rows + a + row * (NCOL * 4)) + t;
-  };
-  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  float w0 = fetch(0), w1 = fetch(1), w2 = fetch(2), w3 = fetch(3);
-  constexpr int CH = EPT < 8 ? EPT : 8;
-#pragma unroll
-  for (int r0 = 0; r0 < EPT; r0 += CH) {
-    float nxt[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) nxt[j] = fetch(r0 + j + 4);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const float x = u[r0 + j];
-      s[0] += pow_abs<PMODE>(x - w0, p, p_int);
-      s[1] += pow_abs<PMODE>(x - w1, p, p_int);
-      s[2] += pow_abs<PMODE>(x - w2, p, p_int);
-      s[3] += pow_abs<PMODE>(x - w3, p, p_int);
-      s[4] += pow_abs<PMODE>(x - nxt[j], p, p_int);
-      w0 = w1; w1 = w2; w2 = w3; w3 = nxt[j];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int q = 0; q < 5; ++q) c[q] = wave_sum_uniform(s[q], lane & 63);
-}
-
-// solve_shift for a full class on five-point windows: the same minimiser of the convex sequence c(k), |k| <= n.
-template <int EPT, int PMODE>
-__device__ __forceinline__ int solve_shift5(const float (&u)[EPT], const float* vbuf, int lane, int n, float sum_u,
-                                            float sum_v, float p, int p_int, float& best) {
-  int lo = -n, hi = n;
-  float guess = rintf(sum_u - sum_v);
-  guess = fminf(fmaxf(guess, (float)lo), (float)hi);
-  int k = __builtin_amdgcn_readfirstlane((int)guess);
-  bool lo_tight = false, hi_tight = false;
-  int step = 4;
-  float c[5];
-  int o = 0;
-  for (int it = 0; it < 64; ++it) {
-    int ln = lane;                       // opaque copy: no lane-derived constants held across iterations
-    asm volatile("" : "+v"(ln));
-    shift_costs5_full<EPT, PMODE>(u, vbuf, ln, k, p, p_int, c);
-    // walk from the centre while the neighbour is strictly cheaper (and inside [lo, hi]): the window is unimodal
-    o = 0;
-    if (c[3] < c[2] && k + 1 <= hi) { o = 1; if (c[4] < c[3] && k + 2 <= hi) o = 2; }
-    else if (c[1] < c[2] && k - 1 >= lo) { o = -1; if (c[0] < c[1] && k - 2 >= lo) o = -2; }
-    // inside the window both neighbours of the minimum are known; on the edge of [lo, hi] there is nothing beyond it
-    if (o > -2 && o < 2) break;
-    if (o == 2 && k + 2 >= hi) break;
-    if (o == -2 && k - 2 <= lo) break;
-    if (o == 2) {
-      lo = k + 2; lo_tight = true;
-      if (hi_tight) { k = lo + ((hi - lo) >> 1); } else { k = min(k + step, hi); step <<= 1; }
-    } else {
-      hi = k - 2; hi_tight = true;
-      if (lo_tight) { k = lo + ((hi - lo) >> 1); } else { k = max(k - step, lo); step <<= 1; }
-    }
-    k = __builtin_amdgcn_readfirstlane(k);
-    o = 0;
-  }
-  best = c[2 + o];
-  return k + o;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Any n (not only n == 64*EPT): the sorted target as PRE-ROTATED, EXTENDED rows.
 //
