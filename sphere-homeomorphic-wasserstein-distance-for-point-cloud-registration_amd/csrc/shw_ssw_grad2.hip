@@ -93,6 +93,7 @@ __global__ __launch_bounds__(128, grad2_waves_per_simd(EPT, FULL)) void ssw_forw
     asm volatile("" : "+v"(ln));
     float pm, p0, pp;
     if constexpr (FULL) shift_costs3_full<EPT, PMODE, 64, HALF>(u, row_t, ln, k, A.p, A.p_int, pm, p0, pp, r_base);
+    else if constexpr (SHW_GRAD2_INC && HALF + 2 <= EPT) shift_costs3_inc<EPT, PMODE, 64, HALF>(u, row_t, ln, n, k, A.p, A.p_int, pm, p0, pp, r_base);
     else shift_costs3<EPT, PMODE, 64, HALF>(u, row_t, ln, n, k, A.p, A.p_int, pm, p0, pp, r_base);
     float* slot = red + (it & 1) * 8;
     if (lane == 0) { slot[wave * 4] = pm; slot[wave * 4 + 1] = p0; slot[wave * 4 + 2] = pp; }

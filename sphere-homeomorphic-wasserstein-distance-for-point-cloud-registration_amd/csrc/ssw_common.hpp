@@ -23,6 +23,15 @@
 #include "../../include/shw.h"
 #include "wave_sort.hpp"
 
+#ifndef SHW_INC_MASK_BY_EXEC
+#define SHW_INC_MASK_BY_EXEC 1
+#endif
+#ifndef SHW_SOLVE_INC
+#define SHW_SOLVE_INC 1
+#endif
+#ifndef SHW_GRAD2_INC
+#define SHW_GRAD2_INC 1
+#endif
 #ifndef SHW_MASK_BY_EXEC
 #define SHW_MASK_BY_EXEC 1      // pads of a partially filled class masked by exec (a kept branch) instead of three selects
 #endif
@@ -218,6 +227,87 @@ __device__ __forceinline__ void shift_costs3(const float (&u)[NR], const float* 
   cp = wave_sum_uniform(sp, lane & 63);
 }
 
+// one fetch of shift_costs3_inc (arguments by value: as captured references the offsets end up as a table in scratch
+// memory read through flat pointers)
+__device__ __forceinline__ float inc_fetch(const char* row, bool before_turn, bool first_column, int a0, int a1, int b0,
+                                           float t0, float tw) {
+  const int a = before_turn ? (first_column ? a0 : a1) : b0;
+  return *reinterpret_cast<const float*>(row + a) + (before_turn ? t0 : tw);
+}
+// the last fetch of a window of EPT + 2 positions (one-wave kernels): it may lie in the third column of the window, or in
+// the second one after the end of the circle
+__device__ __forceinline__ float inc_fetch_last(const char* row, bool before_turn, bool second_column, bool second_after_turn,
+                                                int a1, int a2, int b0, int b1, float t0, float tw) {
+  const int a = before_turn ? (second_column ? a1 : a2) : (second_after_turn ? b1 : b0);
+  return *reinterpret_cast<const float*>(row + a) + (before_turn ? t0 : tw);
+}
+
+// shift_costs3 for any n with 6 VALU per fetched target atom instead of the ~15 of target_unrolled.  The window of a
+// lane (NR + 2 consecutive positions) starts at slot (row0, col0) of the plain rows; while it is no longer than one column
+// (NR + 2 <= EPT: the two-wave training kernel, NR = EPT/2) it meets at most one end of column (the address drops by a
+// constant) and at most one end of the circle (position n: it restarts at slot (0, 0) one turn further on, and is then too
+// short to meet anything else).  With the two per-lane thresholds jr = EPT - row0 and jn = n - q0 prepared once, fetch j is
+//     ds_read(j*256 + (j < jn ? (j < jr ? A0 : A1) : B0)) + (j < jn ? t0 : t0 + 1).
+// A window of EPT + 2 positions (NR = EPT: the one-wave kernels) can reach one column further with its LAST position only
+// (jr >= 1, jn >= 1), which gets its own form.  Pads are masked by exec as in shift_costs3_ext.
+template <int EPT, int PMODE, int NCOL = 64, int NR = EPT>
+__device__ __forceinline__ void shift_costs3_inc(const float (&u)[NR], const float* vbuf, int lane, int n,
+                                                 int k, float p, int p_int, float& cm, float& c0, float& cp,
+                                                 int r_base = 0) {
+  static_assert(NR <= EPT, "a window of at most EPT + 2 positions");
+  int q = lane * EPT + r_base + k - 1;              // in [-n - 1, 64 EPT + n) within [-2n, 3n): two turns at most
+  const int t1 = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
+  q -= t1 * n;
+  const int t2 = (q < 0) ? -1 : ((q >= n) ? 1 : 0);
+  q -= t2 * n;
+  const float t0 = (float)(t1 + t2), tw = t0 + 1.f;
+  const int col0 = ediv<EPT>(q), row0 = q - col0 * EPT;
+  const int jr = EPT - row0, jn = n - q;
+  constexpr int RB = NCOL * 4;                      // bytes per row
+  const int A0 = row0 * RB + (col0 << 2);
+  const int A1 = A0 + 4 - EPT * RB;
+  const int B0 = -jn * RB;
+  const char* rows = reinterpret_cast<const char*>(vbuf);
+  auto fetch = [&](int j) -> float {                // j compile-time after unrolling
+    if (j <= EPT) return inc_fetch(rows + j * RB, j < jn, j < jr, A0, A1, B0, t0, tw);
+    return inc_fetch_last(rows + j * RB, j < jn, j < jr + EPT, j >= jn + EPT, A1, A1 + 4 - EPT * RB, B0, B0 + 4 - EPT * RB,
+                          t0, tw);
+  };
+  const int live_regs = n - lane * EPT - r_base;
+  float sm = 0.f, s0 = 0.f, sp = 0.f;
+  float prev = fetch(0), cur = fetch(1);
+  constexpr int CH = chunk_of(NR);
+#pragma unroll
+  for (int r0 = 0; r0 < NR; r0 += CH) {
+    float nxt[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) nxt[j] = fetch(r0 + j + 2);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float a = pow_abs<PMODE>(u[r0 + j] - prev, p, p_int);
+      const float b = pow_abs<PMODE>(u[r0 + j] - cur, p, p_int);
+      const float c = pow_abs<PMODE>(u[r0 + j] - nxt[j], p, p_int);
+#if SHW_INC_MASK_BY_EXEC
+      if ((r0 + j) < live_regs) {
+        asm volatile("" : "+v"(sm), "+v"(s0), "+v"(sp));
+        sm += a; s0 += b; sp += c;
+      }
+#else
+      const bool live = (r0 + j) < live_regs;
+      sm += live ? a : 0.f;
+      s0 += live ? b : 0.f;
+      sp += live ? c : 0.f;
+#endif
+      prev = cur;
+      cur = nxt[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cm = wave_sum_uniform(sm, lane & 63);
+  c0 = wave_sum_uniform(s0, lane & 63);
+  cp = wave_sum_uniform(sp, lane & 63);
+}
+
 // Fast form of shift_costs3 for n == 64*EPT exactly (every register slot is a real atom, n a power of
 // two).  With base = k-1 = kh*EPT + kl (0 <= kl < EPT) the window position j of lane l is sorted
 // position (l + kh + c)*EPT + row with  row = (kl + j) mod EPT  and carry  c = (kl + j) div EPT in
@@ -289,7 +379,8 @@ __device__ __forceinline__ int solve_shift(const float (&u)[EPT], const float* v
     int ln = lane;                       // opaque copy: no lane-derived constants held across iterations
     asm volatile("" : "+v"(ln));
     if constexpr (FULL) shift_costs3_full<EPT, PMODE>(u, vbuf, ln, k, p, p_int, cm, c0, cp);
-    else shift_costs3<EPT, PMODE>(u, vbuf, ln, n, k, p, p_int, cm, c0, cp);
+    else if constexpr (SHW_SOLVE_INC && EPT <= 16) shift_costs3_inc<EPT, PMODE>(u, vbuf, ln, n, k, p, p_int, cm, c0, cp);
+    else shift_costs3<EPT, PMODE>(u, vbuf, ln, n, k, p, p_int, cm, c0, cp);   // (diagnostic one-wave kernels of the big classes)
     const bool right = (cp < c0) && (k < hi);
     const bool left = !right && (cm < c0) && (k > lo);
     if (!right && !left) break;
