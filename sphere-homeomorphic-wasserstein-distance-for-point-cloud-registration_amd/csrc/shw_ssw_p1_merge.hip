@@ -26,6 +26,7 @@
 // (first merged atom: -|level - med| / lcm) is un-permuted through two LDS staging rows and stored coalesced:
 // every coefficient written exactly once, no atomics (rows feed ssw_backward_points_kernel).  The one-wave
 // search kernel it replaces sorted 64-bit (key, index) items: 3.5 -> see DESIGN.md ms per training step.
+#include "bin_sort.hpp"
 #include "bin_sort_idx.hpp"
 #include "ssw_common.hpp"
 
@@ -62,7 +63,17 @@ __device__ __forceinline__ int wave_min_int(int v, int lane) {
 #ifndef SHW_P1M_CHAINED
 #define SHW_P1M_CHAINED true
 #endif
-constexpr int merge_waves_per_simd(int ept) { return ept <= 16 ? 6 : SHW_P1M_WAVES; }
+#ifndef SHW_P1M_LOSS_BINS
+#define SHW_P1M_LOSS_BINS 8     // loss only: distribution sort from this many keys per lane on (0: never)
+#endif
+constexpr bool loss_sort_binned(int ept) { return SHW_P1M_LOSS_BINS != 0 && ept >= SHW_P1M_LOSS_BINS; }
+constexpr int merge_waves_per_simd(int ept) { return loss_sort_binned(ept) ? 3 : (ept <= 16 ? 6 : SHW_P1M_WAVES); }
+// loss-only LDS floats: the exchange buffer, or the two waves' sort scratch where that is larger
+template <int EPT>
+constexpr int merge_loss_lds_floats() {
+  return loss_sort_binned(EPT) && 2 * (binsort_bins<EPT>() + EPT * kWave) > EPT * 128 ? 2 * (binsort_bins<EPT>() + EPT * kWave)
+                                                                                          : EPT * 128;
+}
 
 template <int EPT, bool GRAD>
 __global__ __launch_bounds__(128, GRAD ? (EPT <= 16 ? 4 : 3) : merge_waves_per_simd(EPT)) void
@@ -76,7 +87,7 @@ ssw_level_median_merge_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
   unsigned short* sidx = reinterpret_cast<unsigned short*>(lds + EPT * 128 + 16);
   // 16 words of cross-wave scratch, one slot per wave each: [0..3] median partial sums (two parities),
   // [4,5] tag counts, [6,7] first keys, [8,9] smallest / [10,11] largest level, [12,13] gap totals, [14,15] costs
-  float* red = lds + EPT * 128;
+  float* red = lds + (GRAD ? EPT * 128 : merge_loss_lds_floats<EPT>());
   int* redi = reinterpret_cast<int*>(red);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,12 +122,26 @@ ssw_level_median_merge_kernel(SswArgs A, int mg, int ng, float inv_lcm) {
     } else {
       float key[EPT];
       load_coords<EPT, false, SHW_P1M_CHAINED>(X, count, lane, U, key);
+      if constexpr (loss_sort_binned(EPT)) {
+        // the distribution sort of the p != 1 kernels on the tagged keys (pads stay +inf: the largest words of the merge);
+        // each wave's counters + staging buffer (12 EPT * 32 B) take the place of the exchange buffer until the barrier
 #pragma unroll
-      for (int r = 0; r < EPT; ++r) {
-        const bool live = key[r] != __builtin_inff();       // load_coords pads with +inf; no coordinate is +inf
-        pk[r] = live ? (((unsigned)as_i(key[r]) & ~1u) | (unsigned)wave) : 0xffffffffu;
+        for (int r = 0; r < EPT; ++r) {
+          const bool live = key[r] != __builtin_inff();
+          key[r] = live ? as_f((int)(((unsigned)as_i(key[r]) & ~1u) | (unsigned)wave)) : key[r];
+        }
+        wave_sort_binned<EPT, false>(key, lane, count, lds + wave * (binsort_bins<EPT>() + CHUNK));
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) pk[r] = (unsigned)as_i(key[r]);
+        __syncthreads();                                    // both sorts done: their scratch becomes the exchange buffer
+      } else {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          const bool live = key[r] != __builtin_inff();       // load_coords pads with +inf; no coordinate is +inf
+          pk[r] = live ? (((unsigned)as_i(key[r]) & ~1u) | (unsigned)wave) : 0xffffffffu;
+        }
+        wave_sort<EPT>(pk, lane);
       }
-      wave_sort<EPT>(pk, lane);
     }
   }
   // ---- merge the two sorted sequences: flip stage between the waves, the rest inside each wave ----
@@ -261,7 +286,7 @@ static int launch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, 
     hipLaunchKernelGGL((ssw_level_median_merge_kernel<EPT, true>), dim3((unsigned)total), dim3(128), lds, stream, A, mg,
                        ng, inv_lcm);
   } else {
-    const size_t lds = (size_t)(EPT * 128 + 16) * sizeof(float);
+    const size_t lds = (size_t)(merge_loss_lds_floats<EPT>() + 16) * sizeof(float);
     hipLaunchKernelGGL((ssw_level_median_merge_kernel<EPT, false>), dim3((unsigned)total), dim3(128), lds, stream, A,
                        mg, ng, inv_lcm);
   }
