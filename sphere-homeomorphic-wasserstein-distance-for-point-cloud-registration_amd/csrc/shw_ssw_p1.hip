@@ -223,6 +223,7 @@ static int launch_level_median(SswArgs& A, hipStream_t stream) {
 int dispatch_level_median_merge(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream);
 int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream);   // shw_ssw_p1_coop.hip
 bool level_median_coop_trains(int n, int m);
+int level_median_coop_slots(int total);
 
 // SHW_P1_SEARCH_KERNEL=1 (diagnostic): use the one-wave search kernel at every size
 static bool p1_search_kernel_forced() {
@@ -243,7 +244,11 @@ int dispatch_level_median(SswArgs& A, hipStream_t stream) {
   // cooperative kernel (one distribution sort of the tagged concatenation, shw_ssw_p1_coop.hip): every shape above 2048
   // points; at or below, the loss from 1025 merged atoms on (measured at n = m = 2048 / 1024: 0.42 / 0.20 ms against the
   // merge kernel's 0.54 / 0.25) -- training stays with the merge kernel there (0.97 / 0.42 against 0.94 / 0.45 ms)
-  bool coop = small ? (!grad && A.n + A.m > 1024) : (!grad || level_median_coop_trains(A.n, A.m));
+  // round 3: ... unless the cooperative kernel's class (20 / 24 / 32 merged atoms per lane) is smaller than the merge
+  // kernel's two power-of-two halves by more than the 12 % the merge kernel is faster per slot (n = m = 1200: 2560 against
+  // 4096 slots, 0.52 against 0.74 ms per step)
+  bool coop = small ? (A.n + A.m > 1024 && (!grad || 9 * level_median_coop_slots(A.n + A.m) < 8 * 128 * ept_for(A.n, A.m)))
+                    : (!grad || level_median_coop_trains(A.n, A.m));
   if (p1_kernel_forced() == 1 && A.n + A.m > 1024) coop = true;
   if (p1_kernel_forced() == 2 && small) coop = false;
   if (p1_search_kernel_forced()) coop = false;

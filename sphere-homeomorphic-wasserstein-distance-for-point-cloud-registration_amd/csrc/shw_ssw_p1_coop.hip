@@ -82,7 +82,7 @@ __global__ __launch_bounds__(W * 64) void ssw_level_median_coop_kernel(SswArgs A
   coop_zero_counters<EPT, W, KPB>(cnt, gl);
   // ---- project the concatenated clouds: lane owns atoms r*64W + gl ------------------------------------------------
   float key[EPT];
-  constexpr int CH = 8;
+  constexpr int CH = chunk_of(EPT);
 #pragma unroll
   for (int r0 = 0; r0 < EPT; r0 += CH) {
     float px[CH], py[CH], pz[CH];
@@ -257,23 +257,43 @@ static int launch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, h
 // training form available?  (12 bytes of LDS per merged slot up to n + m = 8192, 9 above: four keys per bin)
 bool level_median_coop_trains(int n, int m) { return next_pow2(n + m) <= 16384; }
 
-// p = 1, 2048 < max(n, m) <= 8192 (called from dispatch_level_median, shw_ssw_p1.hip); coef_s != NULL: + coefficients
+// p = 1 (called from dispatch_level_median, shw_ssw_p1.hip); coef_s != NULL: + coefficients.  W waves of 20 / 24 / 32 merged
+// atoms per lane: the smallest of the 12 classes (1280 ... 16384 slots) that holds n + m (round 3: 1200 + 1200 points
+// pay for 2560 slots, not 4096; SHW_KPL_CLASSES=0 keeps 32 per lane)
+static void level_median_coop_class(int total, int& W, int& ept) {
+  static const bool fine = [] { const char* v = getenv("SHW_KPL_CLASSES"); return !(v && v[0] == '0'); }();
+  W = 0; ept = 0;
+  for (int w = 1; w <= 8 && W == 0; w *= 2) {
+    for (int e : {20, 24, 32}) {
+      if ((e == 32 || fine) && 64 * w * e >= total) { W = w; ept = e; break; }
+    }
+  }
+}
+// merged slots of the class that serves n + m atoms (0: none)
+int level_median_coop_slots(int total) {
+  int W, ept;
+  level_median_coop_class(total, W, ept);
+  return 64 * W * ept;
+}
+
 int dispatch_level_median_coop(SswArgs& A, int mg, int ng, float inv_lcm, hipStream_t stream) {
-  const int padded = next_pow2(A.n + A.m);
   const bool grad = A.coef_s != nullptr;
-  switch (padded / 2048) {
+  int W, ept;
+  level_median_coop_class(A.n + A.m, W, ept);
+#define SHW_P1C_CASE(WW, EE)                                                                        \
+  case WW * 100 + EE:                                                                               \
+    return grad ? launch_level_median_coop<EE, WW, true>(A, mg, ng, inv_lcm, stream)                \
+                : launch_level_median_coop<EE, WW, false>(A, mg, ng, inv_lcm, stream)
+  switch (W * 100 + ept) {
 #ifndef SHW_DEV_ONLY_EPT
-    case 1: return grad ? launch_level_median_coop<32, 1, true>(A, mg, ng, inv_lcm, stream)
-                        : launch_level_median_coop<32, 1, false>(A, mg, ng, inv_lcm, stream);
-    case 2: return grad ? launch_level_median_coop<32, 2, true>(A, mg, ng, inv_lcm, stream)
-                        : launch_level_median_coop<32, 2, false>(A, mg, ng, inv_lcm, stream);
-    case 4: return grad ? launch_level_median_coop<32, 4, true>(A, mg, ng, inv_lcm, stream)
-                        : launch_level_median_coop<32, 4, false>(A, mg, ng, inv_lcm, stream);
-    case 8: return grad ? launch_level_median_coop<32, 8, true>(A, mg, ng, inv_lcm, stream)
-                        : launch_level_median_coop<32, 8, false>(A, mg, ng, inv_lcm, stream);
+    SHW_P1C_CASE(1, 20); SHW_P1C_CASE(1, 24); SHW_P1C_CASE(1, 32);
+    SHW_P1C_CASE(2, 20); SHW_P1C_CASE(2, 24); SHW_P1C_CASE(2, 32);
+    SHW_P1C_CASE(4, 20); SHW_P1C_CASE(4, 24); SHW_P1C_CASE(4, 32);
+    SHW_P1C_CASE(8, 20); SHW_P1C_CASE(8, 24); SHW_P1C_CASE(8, 32);
 #endif
     default: return (int)hipErrorInvalidValue;
   }
+#undef SHW_P1C_CASE
 }
 
 }  // namespace shw

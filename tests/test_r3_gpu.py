@@ -442,3 +442,48 @@ def test_chamfer_gradients_are_bit_identical_from_run_to_run(shw):
     ((d.min(2).values.mean(1) + d.min(1).values.mean(1)) * w.double()).sum().backward()
     for got, ref in ((runs[0][0], xd.grad), (runs[0][1], yd.grad)):
         assert (got.cpu().double() - ref).abs().max() < 1e-5 * ref.abs().max()
+
+
+# ------------------------------------------------------------------------------- p = 1: classes between powers of two
+@pytest.mark.parametrize("n,m", [(513, 513), (600, 600), (640, 640), (700, 800), (1200, 1200), (1280, 1280), (1500, 1500),
+                                 (1536, 1536), (1200, 900), (2500, 2500), (2560, 2560), (3000, 3000), (5000, 5000),
+                                 (6000, 6144)])
+def test_p1_cooperative_kernel_classes_against_cpu_oracle(shw, n, m):
+    """The cooperative p = 1 kernel picks W waves of 20 / 24 / 32 merged atoms per lane (1280 ... 16384 slots): values of
+    every class and its edges against the level-median restatement (3e-5 per slice), and the loss of the training launch
+    against the loss-only launch (different kernels below 2048 points, the same above)."""
+    from oracle import exact_shift
+    g = torch.Generator().manual_seed(7000 + n + m)
+    L = 6
+    x, y, U = unit_cloud(g, n), unit_cloud(g, m), directions(g, L)
+    _, cost, _ = shw.ssw_pair_losses(x.cuda().unsqueeze(0), y.cuda().unsqueeze(0), U.cuda(), p=1, return_slices=True)
+    cu = exact_shift.circle_coords(x.numpy(), U.numpy())
+    cv = exact_shift.circle_coords(y.numpy(), U.numpy())
+    ref = np.array([exact_shift.w1_level_median(cu[l], cv[l]) for l in range(L)])
+    assert np.allclose(cost[0].cpu().numpy(), ref, rtol=3e-5, atol=1e-9)
+    xs = x.cuda().requires_grad_(True)
+    pair, cost_t, _ = shw.ssw_pair_losses(xs.unsqueeze(0), y.cuda().unsqueeze(0), U.cuda(), p=1, return_slices=True)
+    pair.sum().backward()
+    assert np.allclose(cost_t[0].detach().cpu().numpy(), ref, rtol=3e-5, atol=1e-9)
+    assert torch.isfinite(xs.grad).all()
+
+
+@pytest.mark.parametrize("n,m", [(600, 600), (1200, 1200), (1500, 1400), (2500, 2500), (3000, 2200), (5000, 5000)])
+def test_p1_training_classes_against_autograd_of_the_restatement(shw, n, m):
+    """Gradients of the cooperative p = 1 training kernel in the 20 / 24 keys-per-lane classes (merged 1200 -> 1 x 20,
+    2400 -> 2 x 20, 2900 -> 2 x 24, 5000 -> 4 x 20, 5200 -> 4 x 24, 10000 -> 8 x 20; below 2048 points it takes over from the
+    merge kernel where its class is the smaller one) against autograd of the reference's restatement."""
+    from oracle import ref_mirror
+    from helpers.compare import grad_close
+    g = torch.Generator().manual_seed(17 * n + m)
+    x, y = unit_cloud(g, n), unit_cloud(g, m)
+    U = directions(g, 4)
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    val = shw.sliced_cost(xs, ys, U.cuda(), p=1)
+    val.backward()
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    ref = ref_mirror.sliced_cost(xc, yc, U, p=1)
+    ref.backward()
+    assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-7
+    grad_close(xs.grad.cpu().numpy(), xc.grad.numpy(), loose=0.1)
+    grad_close(ys.grad.cpu().numpy(), yc.grad.numpy(), loose=0.1)
