@@ -44,6 +44,8 @@ if has sweep; then
   echo "== size sweeps"
   timeout -k 10 600 python3 tools/size_sweep.py 2,1 2>&1 | grep -v amdgpu.ids > $OUT/size_sweep.txt; cat $OUT/size_sweep.txt
   timeout -k 10 300 python3 tools/size_sweep_mid.py 2>&1 | grep -v amdgpu.ids > $OUT/size_sweep_mid.txt
+  timeout -k 10 300 python3 tools/size_sweep_small.py 2>&1 | grep -v amdgpu.ids > $OUT/size_sweep_small.txt
+  timeout -k 10 300 python3 tools/size_sweep_p1.py 2>&1 | grep -v amdgpu.ids > $OUT/size_sweep_p1.txt
 fi
 if has modes; then
   echo "== bench.py secondary modes"
