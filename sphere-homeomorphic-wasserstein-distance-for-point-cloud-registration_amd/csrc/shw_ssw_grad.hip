@@ -226,6 +226,88 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
   }
 }
 
+// The same for clouds whose size is a multiple of 4 (round 3, late): a lane owns FOUR consecutive points and reads their
+// coefficients of one slice as one 16-byte load (1 KB per wave-load instead of 256 B), SHW_BWD4_INFLIGHT slices in flight:
+// four times the bytes in flight per lane.  A workgroup owns 256 consecutive points; its 4 waves split the slices 4 ways;
+// partial sums added in wave order through LDS as above.
+#ifndef SHW_BWD4_INFLIGHT
+#define SHW_BWD4_INFLIGHT 4
+#endif
+__global__ __launch_bounds__(256) void ssw_backward_points4_kernel(const float* __restrict__ xs,
+                                                                   const float* __restrict__ xt,
+                                                                   const float* __restrict__ dirs,
+                                                                   const float* __restrict__ coef_s,
+                                                                   const float* __restrict__ coef_t, int n, int m,
+                                                                   int slices, long u_pair_stride, float scale,
+                                                                   const float* __restrict__ pair_w,
+                                                                   const float* __restrict__ total_w,
+                                                                   float* __restrict__ grad_xs,
+                                                                   float* __restrict__ grad_xt, int chunks_s) {
+  __shared__ float part[4][12][64];
+  const int b = blockIdx.y;
+  const bool is_t = (int)blockIdx.x >= chunks_s;
+  const int chunk = is_t ? blockIdx.x - chunks_s : blockIdx.x;
+  const int cnt = is_t ? m : n;                              // a multiple of 4
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i0 = chunk * 256 + lane * 4;                     // first of the lane's four points
+  const float* X = (is_t ? xt : xs) + (long)b * cnt * 3;
+  const float* C = (is_t ? coef_t : coef_s) + (long)b * slices * cnt;
+  float* G = (is_t ? grad_xt : grad_xs) + (long)b * cnt * 3;
+  const float* Ub = dirs + (long)b * u_pair_stride;
+  const int ic = min(i0, cnt - 4);
+  float p[12], g[12];
+  {
+    const float4* X4 = reinterpret_cast<const float4*>(X + 3 * ic);   // 12 floats = 3 x 16 B (ic a multiple of 4)
+    const float4 q0 = X4[0], q1 = X4[1], q2 = X4[2];
+    p[0] = q0.x; p[1] = q0.y; p[2] = q0.z; p[3] = q0.w; p[4] = q1.x; p[5] = q1.y; p[6] = q1.z; p[7] = q1.w;
+    p[8] = q2.x; p[9] = q2.y; p[10] = q2.z; p[11] = q2.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) g[k] = 0.f;
+  const float inv_two_pi = 0.159154936671257019f;
+  auto add = [&](const float4 c4, const float* U) {
+    const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float px = p[3 * q], py = p[3 * q + 1], pz = p[3 * q + 2];
+      const float a = fmaf(pz, U[4], fmaf(py, U[2], px * U[0]));
+      const float bb = fmaf(pz, U[5], fmaf(py, U[3], px * U[1]));
+      const float r2 = fmaf(a, a, bb * bb);                  // (0, 0) projection: zero gradient, see above
+      const float w = r2 > 0.f ? c[q] * inv_two_pi / r2 : 0.f;
+      g[3 * q] = fmaf(w, fmaf(a, U[1], -bb * U[0]), g[3 * q]);
+      g[3 * q + 1] = fmaf(w, fmaf(a, U[3], -bb * U[2]), g[3 * q + 1]);
+      g[3 * q + 2] = fmaf(w, fmaf(a, U[5], -bb * U[4]), g[3 * q + 2]);
+    }
+  };
+  constexpr int F = SHW_BWD4_INFLIGHT;
+  int l = wave;
+  for (; l + 4 * (F - 1) < slices; l += 4 * F) {             // F slices of this wave per trip, loads first
+    float4 c[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) c[j] = *reinterpret_cast<const float4*>(C + (long)(l + 4 * j) * cnt + ic);
+#pragma unroll
+    for (int j = 0; j < F; ++j) add(c[j], Ub + (long)(l + 4 * j) * 6);
+  }
+  for (; l < slices; l += 4) add(*reinterpret_cast<const float4*>(C + (long)l * cnt + ic), Ub + (long)l * 6);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) part[wave][k][lane] = g[k];
+  __syncthreads();
+  if (wave == 0 && i0 < cnt) {
+    float up = (pair_w || total_w) ? 0.f : 1.f;
+    if (pair_w) up += pair_w[b];
+    if (total_w) up += total_w[0];
+    const float sc = scale * up;
+    float o[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = (((part[0][k][lane] + part[1][k][lane]) + part[2][k][lane]) + part[3][k][lane]) * sc;
+    float4* G4 = reinterpret_cast<float4*>(G + 3 * i0);
+    G4[0] = make_float4(o[0], o[1], o[2], o[3]);
+    G4[1] = make_float4(o[4], o[5], o[6], o[7]);
+    G4[2] = make_float4(o[8], o[9], o[10], o[11]);
+  }
+}
+
 int launch_forward_grad_kv128(SswArgs& A, hipStream_t stream);
 
 template <int EPT, int WAVES>
@@ -295,6 +377,22 @@ int launch_backward_points(const float* xs, const float* xt, const float* dirs, 
                            const float* coef_t, int pairs, int n, int m, int slices, long u_pair_stride,
                            float scale, const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt,
                            hipStream_t stream) {
+  // sizes that are multiples of 4 (16-byte aligned rows and points): four points per lane, 16-byte loads
+  static const bool wide_ok = [] { const char* v = getenv("SHW_BWD_WIDE"); return !(v && v[0] == '0'); }();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(xt) | reinterpret_cast<uintptr_t>(coef_s) |
+                         reinterpret_cast<uintptr_t>(coef_t) | reinterpret_cast<uintptr_t>(grad_xs) |
+                         reinterpret_cast<uintptr_t>(grad_xt)) & 15) == 0;
+  if (wide_ok && aligned && n % 4 == 0 && m % 4 == 0 && n >= 4 && m >= 4) {
+    const int c_s = (n + 255) / 256, c_t = (m + 255) / 256;
+    for (int b0 = 0; b0 < pairs; b0 += 65535) {
+      const int nb = pairs - b0 < 65535 ? pairs - b0 : 65535;
+      hipLaunchKernelGGL(ssw_backward_points4_kernel, dim3(c_s + c_t, nb), dim3(256), 0, stream,
+                         xs + (long)b0 * n * 3, xt + (long)b0 * m * 3, dirs + (long)b0 * u_pair_stride,
+                         coef_s + (long)b0 * slices * n, coef_t + (long)b0 * slices * m, n, m, slices, u_pair_stride,
+                         scale, pair_w ? pair_w + b0 : nullptr, total_w, grad_xs + (long)b0 * n * 3, grad_xt + (long)b0 * m * 3, c_s);
+    }
+    return (int)hipGetLastError();
+  }
   const int chunks_s = (n + 63) / 64, chunks_t = (m + 63) / 64;
   // pairs ride on gridDim.y (<= 65535): larger batches go out as several launches over pair blocks
   for (int b0 = 0; b0 < pairs; b0 += 65535) {
