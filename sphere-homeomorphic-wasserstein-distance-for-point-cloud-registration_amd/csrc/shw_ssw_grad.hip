@@ -233,7 +233,10 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
 #ifndef SHW_BWD4_INFLIGHT
 #define SHW_BWD4_INFLIGHT 4
 #endif
-__global__ __launch_bounds__(256) void ssw_backward_points4_kernel(const float* __restrict__ xs,
+#ifndef SHW_BWD4_WAVES
+#define SHW_BWD4_WAVES 4      // waves per workgroup = ways the slices are split
+#endif
+__global__ __launch_bounds__(64 * SHW_BWD4_WAVES) void ssw_backward_points4_kernel(const float* __restrict__ xs,
                                                                    const float* __restrict__ xt,
                                                                    const float* __restrict__ dirs,
                                                                    const float* __restrict__ coef_s,
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(256) void ssw_backward_points4_kernel(const float* 
                                                                    const float* __restrict__ total_w,
                                                                    float* __restrict__ grad_xs,
                                                                    float* __restrict__ grad_xt, int chunks_s) {
-  __shared__ float part[4][12][64];
+  constexpr int NW = SHW_BWD4_WAVES;
+  __shared__ float part[NW][12][64];
   const int b = blockIdx.y;
   const bool is_t = (int)blockIdx.x >= chunks_s;
   const int chunk = is_t ? blockIdx.x - chunks_s : blockIdx.x;
@@ -282,14 +286,14 @@ __global__ __launch_bounds__(256) void ssw_backward_points4_kernel(const float* 
   };
   constexpr int F = SHW_BWD4_INFLIGHT;
   int l = wave;
-  for (; l + 4 * (F - 1) < slices; l += 4 * F) {             // F slices of this wave per trip, loads first
+  for (; l + NW * (F - 1) < slices; l += NW * F) {             // F slices of this wave per trip, loads first
     float4 c[F];
 #pragma unroll
-    for (int j = 0; j < F; ++j) c[j] = *reinterpret_cast<const float4*>(C + (long)(l + 4 * j) * cnt + ic);
+    for (int j = 0; j < F; ++j) c[j] = *reinterpret_cast<const float4*>(C + (long)(l + NW * j) * cnt + ic);
 #pragma unroll
-    for (int j = 0; j < F; ++j) add(c[j], Ub + (long)(l + 4 * j) * 6);
+    for (int j = 0; j < F; ++j) add(c[j], Ub + (long)(l + NW * j) * 6);
   }
-  for (; l < slices; l += 4) add(*reinterpret_cast<const float4*>(C + (long)l * cnt + ic), Ub + (long)l * 6);
+  for (; l < slices; l += NW) add(*reinterpret_cast<const float4*>(C + (long)l * cnt + ic), Ub + (long)l * 6);
 #pragma unroll
   for (int k = 0; k < 12; ++k) part[wave][k][lane] = g[k];
   __syncthreads();
@@ -300,7 +304,12 @@ __global__ __launch_bounds__(256) void ssw_backward_points4_kernel(const float* 
     const float sc = scale * up;
     float o[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) o[k] = (((part[0][k][lane] + part[1][k][lane]) + part[2][k][lane]) + part[3][k][lane]) * sc;
+    for (int k = 0; k < 12; ++k) {
+      float acc = part[0][k][lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) acc += part[w][k][lane];  // wave order: fixed
+      o[k] = acc * sc;
+    }
     float4* G4 = reinterpret_cast<float4*>(G + 3 * i0);
     G4[0] = make_float4(o[0], o[1], o[2], o[3]);
     G4[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -386,7 +395,7 @@ int launch_backward_points(const float* xs, const float* xt, const float* dirs, 
     const int c_s = (n + 255) / 256, c_t = (m + 255) / 256;
     for (int b0 = 0; b0 < pairs; b0 += 65535) {
       const int nb = pairs - b0 < 65535 ? pairs - b0 : 65535;
-      hipLaunchKernelGGL(ssw_backward_points4_kernel, dim3(c_s + c_t, nb), dim3(256), 0, stream,
+      hipLaunchKernelGGL(ssw_backward_points4_kernel, dim3(c_s + c_t, nb), dim3(64 * SHW_BWD4_WAVES), 0, stream,
                          xs + (long)b0 * n * 3, xt + (long)b0 * m * 3, dirs + (long)b0 * u_pair_stride,
                          coef_s + (long)b0 * slices * n, coef_t + (long)b0 * slices * m, n, m, slices, u_pair_stride,
                          scale, pair_w ? pair_w + b0 : nullptr, total_w, grad_xs + (long)b0 * n * 3, grad_xt + (long)b0 * m * 3, c_s);
