@@ -487,3 +487,35 @@ def test_p1_training_classes_against_autograd_of_the_restatement(shw, n, m):
     assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-7
     grad_close(xs.grad.cpu().numpy(), xc.grad.numpy(), loose=0.1)
     grad_close(ys.grad.cpu().numpy(), yc.grad.numpy(), loose=0.1)
+
+
+# ------------------------------------------------------------------------------- backward-points kernel, four points per lane
+_BWD_WIDE_SCRIPT = r"""
+import json, sys, hashlib, torch
+sys.path.insert(0, sys.argv[1])
+import shw_amd
+out = {}
+for (B, n, m, L, p) in ((3, 1200, 1200, 37, 2), (2, 2048, 1024, 16, 1), (1, 4, 8, 5, 2), (2, 3000, 3000, 9, 2), (2, 1200, 900, 8, 2)):
+    g = torch.Generator().manual_seed(100 * n + m)
+    x = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=g), dim=-1).cuda().requires_grad_(True)
+    y = torch.nn.functional.normalize(torch.randn(B, m, 3, generator=g), dim=-1).cuda().requires_grad_(True)
+    U = shw_amd.stiefel_frames(torch.randn(B, L, 3, 2, generator=g).cuda())
+    w = torch.linspace(0.5, 1.5, B).cuda()
+    (shw_amd.ssw_pair_losses(x, y, U, p) * w).sum().backward()
+    out[f"{n}x{m}p{p}"] = [hashlib.sha256(t.grad.cpu().numpy().tobytes()).hexdigest() for t in (x, y)]
+print(json.dumps(out))
+"""
+
+
+def test_wide_backward_points_kernel_is_bit_identical_to_the_one_point_per_lane_kernel(shw):
+    """Sizes that are multiples of 4 take `ssw_backward_points4_kernel` (a lane owns four consecutive points, 16-byte
+    coefficient loads).  It adds the slices of a point in the same order as the one-point-per-lane kernel
+    (`SHW_BWD_WIDE=0`): the gradients of both clouds must be the same BITS, for equal and unequal sizes, p = 1 and 2, sizes
+    above 2048 and the smallest size that qualifies."""
+    res = {}
+    for wide in ("0", "1"):
+        env = dict(os.environ, SHW_BWD_WIDE=wide)
+        r = subprocess.run([sys.executable, "-c", _BWD_WIDE_SCRIPT, ROOT], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[wide] = json.loads(r.stdout.strip().split("\n")[-1])
+    assert res["0"] == res["1"]
