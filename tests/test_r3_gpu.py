@@ -519,3 +519,45 @@ def test_wide_backward_points_kernel_is_bit_identical_to_the_one_point_per_lane_
         assert r.returncode == 0, r.stderr[-3000:]
         res[wide] = json.loads(r.stdout.strip().split("\n")[-1])
     assert res["0"] == res["1"]
+
+
+# ------------------------------------------------------------------------------- SHW_KPL_CLASSES=0 against the default
+_KPL_SCRIPT = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import shw_amd
+out = {}
+for (n, p) in ((600, 2), (1200, 2), (1500, 3), (1700, 2), (3000, 2), (5000, 2), (600, 1), (1200, 1), (1500, 1), (3000, 1), (5000, 1)):
+    g = torch.Generator().manual_seed(11 * n + int(p))
+    x = torch.nn.functional.normalize(torch.randn(2, n, 3, generator=g), dim=-1).cuda().requires_grad_(True)
+    y = torch.nn.functional.normalize(torch.randn(2, n, 3, generator=g), dim=-1).cuda().requires_grad_(True)
+    U = shw_amd.stiefel_frames(torch.randn(2, 6, 3, 2, generator=g).cuda())
+    pair, cost, _ = shw_amd.ssw_pair_losses(x, y, U, p, return_slices=True)
+    pair.sum().backward()
+    with torch.no_grad():
+        _, cost_fwd, _ = shw_amd.ssw_pair_losses(x.detach(), y.detach(), U, p, return_slices=True)
+    out[f"{n}p{p}"] = {"cost": cost.detach().cpu().tolist(), "cost_fwd": cost_fwd.cpu().tolist(),
+                       "gx": x.grad.cpu().numpy().tolist(), "gy": y.grad.cpu().numpy().tolist()}
+print(json.dumps(out))
+"""
+
+
+def test_keys_per_lane_classes_agree_with_the_power_of_two_classes(shw):
+    """`SHW_KPL_CLASSES=0` keeps only the power-of-two keys-per-lane classes; the default adds 12 / 20 / 24 / 28 keys per lane
+    below 2048 points, 20 / 24 above, and 20 / 24 merged atoms per lane in the cooperative p = 1 kernel.  Different kernels
+    (and below 2048 points at p = 1 a different family: merge against cooperative) on the same seeded clouds: per-slice costs
+    of the loss-only and of the training launch within 3e-6, gradients as `grad_close`."""
+    from helpers.compare import grad_close
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, SHW_KPL_CLASSES=flag)
+        r = subprocess.run([sys.executable, "-c", _KPL_SCRIPT, ROOT], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = json.loads(r.stdout.strip().split("\n")[-1])
+    for key in res["0"]:
+        a, b = res["0"][key], res["1"][key]
+        for f in ("cost", "cost_fwd"):
+            ca, cb = np.array(a[f]), np.array(b[f])
+            assert np.all(np.abs(ca - cb) <= 3e-6 * np.abs(cb) + 1e-12), (key, f)
+        for f in ("gx", "gy"):
+            grad_close(np.array(a[f]), np.array(b[f]), strict=2e-5, loose=5e-2, frac=0.002)
