@@ -215,10 +215,12 @@ class _PairLosses(torch.autograd.Function):
             ctx.set_materialize_grads(False)
         else:
             ws.release()                            # stream-ordered: the next lease is on the same stream
-        return out[:B], out[B:B + 1], cost2d, shift2d
+        # (the first pair's loss as a 0-dim OUTPUT: the per-pair call shape returns it, and indexing pair[0] outside would
+        #  cost a SelectBackward node -- a zero fill and a copy per step, two of the notebooks' eleven launches)
+        return out[:B], out[B:B + 1], cost2d, shift2d, out[0:1].view(())
 
     @staticmethod
-    def backward(ctx, g_pair, g_total, _g_cost, _g_shift):
+    def backward(ctx, g_pair, g_total, _g_cost, _g_shift, g_first=None):
         lib = _lib.load()
         Xs_c, Xt_c, Us_c = ctx.saved_tensors
         ws = ctx.lease.ws
@@ -226,10 +228,16 @@ class _PairLosses(torch.autograd.Function):
         dev = Xs_c.device
         gxs = torch.empty_like(Xs_c)
         gxt = torch.empty_like(Xt_c)
-        if g_pair is None and g_total is None:
+        if g_pair is None and g_total is None and g_first is None:
             return (None,) * 9
         # the upstream gradients go to the kernel as they are: row b is scaled by g_pair[b] + g_total[0] there
         gp = g_pair.to(torch.float32).contiguous() if g_pair is not None else None
+        if g_first is not None:                     # gradient of the 0-dim first-pair output: belongs to row 0
+            if gp is None and B == 1:
+                gp = g_first.to(torch.float32).reshape(1)
+            else:
+                gp = gp.clone() if gp is not None else torch.zeros(B, dtype=torch.float32, device=dev)
+                gp[0] += g_first.to(torch.float32)
         gt = g_total.to(torch.float32).contiguous() if g_total is not None else None
         with torch.cuda.device(dev):
             _lib.check(lib.shw_ssw_backward_points(Xs_c.data_ptr(), Xt_c.data_ptr(), Us_c.data_ptr(),
@@ -251,7 +259,8 @@ def _check_weights(name, w, count, B, dev):
     return w.detach().contiguous()
 
 
-def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weights=None, return_total=False):
+def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weights=None, return_total=False,
+                    return_first=False):
     """Core op: batched clouds (B,n,3), (B,m,3); directions (B,L,3,2) or shared (L,3,2); optional weights
     (n,) / (B,n) and (m,) / (B,m).
     Returns (B,) per-pair losses = mean over slices of W_p^p on the slice circle
@@ -275,8 +284,10 @@ def ssw_pair_losses(Xs, Xt, Us, p=2, return_slices=False, u_weights=None, v_weig
     # evaluation under torch.no_grad() on inputs that still carry requires_grad must not run the
     # training kernel / allocate the coefficient scratch
     need_grad = torch.is_grad_enabled() and (Xs.requires_grad or Xt.requires_grad)
-    pair, total, cost, shift = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared, wu, wv, need_grad,
-                                                 bool(return_slices))
+    pair, total, cost, shift, first = _PairLosses.apply(Xs, Xt, Us.detach(), float(p), shared, wu, wv, need_grad,
+                                                        bool(return_slices))
+    if return_first:                                # 0-dim loss of the first pair (the per-pair call shape)
+        return first
     if return_total:
         return pair, total
     if return_slices:
@@ -297,8 +308,8 @@ def sliced_cost(Xs, Xt, Us, p=2, u_weights=None, v_weights=None):
     over pairs of the per-pair means (_fast.py:291-293).  Batched p == 1, which raises in the
     reference, is evaluated pair-wise here (documented extension)."""
     if Xs.dim() == 2:
-        pair = ssw_pair_losses(Xs.unsqueeze(0), Xt.unsqueeze(0), Us, p, u_weights=u_weights, v_weights=v_weights)
-        return pair[0]
+        return ssw_pair_losses(Xs.unsqueeze(0), Xt.unsqueeze(0), Us, p, u_weights=u_weights, v_weights=v_weights,
+                               return_first=True)
     _, total = ssw_pair_losses(Xs, Xt, Us, p, u_weights=u_weights, v_weights=v_weights, return_total=True)
     return total
 
