@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void chamfer_nn_kernel(const float* __restrict
     for (; j + 4 <= cnt; j += 4) {
       // compares and selects issue at 1.78 ns against 1.0 ns for the arithmetic: the minimum of a group of four
       // candidates is compared with the best so far (v_min3 + v_min + one compare), and only a group that improves some
-      // lane's best goes through the four compare-select pairs that find WHICH candidate did, first one first (strict <:
-      // the first minimum wins, as argmin does).  The k-th candidate is a record with probability 1/k: rare after a while
+      // lane's best looks for WHICH candidate attains it, first one first (strict <: the first minimum wins, as argmin
+      // does).  The k-th candidate is a record with probability 1/k: rare after a while
       float d[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -56,13 +56,10 @@ __global__ __launch_bounds__(256) void chamfer_nn_kernel(const float* __restrict
         d[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
       }
       const float g = fminf(fminf(fminf(d[0], d[1]), d[2]), d[3]);
-      if (g < best) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool lt = d[u] < best;
-          best = lt ? d[u] : best;
-          arg = lt ? base + j + u : arg;
-        }
+      if (g < best) {                                     // (per lane: only the lanes the group improves)
+        best = g;
+        const int u = d[0] == g ? 0 : (d[1] == g ? 1 : (d[2] == g ? 2 : 3));   // the first candidate that attains it
+        arg = base + j + u;
       }
     }
     for (; j < cnt; ++j) {
