@@ -171,6 +171,7 @@ class GraphedStep:
         self._calls = 0
         self._graph = None
         self._loss = None
+        self._ones = None
         for group in optimizer.param_groups:
             if not group.get("capturable", False):
                 raise RuntimeError("the optimizer must be created with capturable=True to be replayed in a hipGraph")
@@ -178,7 +179,11 @@ class GraphedStep:
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn()
-        loss.sum().backward()
+        # the root gradient is a static tensor of ones (allocated on the first, eager call) and a 0-dim loss is not summed:
+        # `loss.sum().backward()` costs a reduction kernel and a fill kernel per step, two launches of the notebooks' eleven
+        if self._ones is None or self._ones.shape != loss.shape:
+            self._ones = torch.ones_like(loss)
+        torch.autograd.backward(loss, grad_tensors=self._ones)
         self.optimizer.step()
         return loss.detach()
 
