@@ -7,7 +7,7 @@ NAME=$1; UNIT=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CSRC=$(ls -d $ROOT/sphere*_amd/csrc)
 mkdir -p $ROOT/gpurun_variants/obj
-NOSLP=-fno-slp-vectorize; [ "$UNIT" = shw_ssw_grad2 ] && NOSLP=      # as the Makefile (SLP_UNITS)
+NOSLP=-fno-slp-vectorize; [ "$UNIT" = shw_ssw_grad2_m32 ] && NOSLP=      # as the Makefile (SLP_UNITS)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wall -Wno-unused-function $NOSLP "$@" \
   -c -o $ROOT/gpurun_variants/obj/$NAME.o $CSRC/$UNIT.hip
 OTHERS=$(ls $CSRC/build/*.o | grep -v "/$UNIT.o")
