@@ -387,11 +387,16 @@ int launch_backward_points(const float* xs, const float* xt, const float* dirs, 
                            float scale, const float* pair_w, const float* total_w, float* grad_xs, float* grad_xt,
                            hipStream_t stream) {
   // sizes that are multiples of 4 (16-byte aligned rows and points): four points per lane, 16-byte loads
-  static const bool wide_ok = [] { const char* v = getenv("SHW_BWD_WIDE"); return !(v && v[0] == '0'); }();
+  // SHW_BWD_WIDE=0: never; =2: whenever sizes and alignment allow (tests); default: when the grid also fills the chip
+  static const int wide_mode = [] { const char* v = getenv("SHW_BWD_WIDE"); return v ? (v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1)) : 1; }();
+  const bool wide_ok = wide_mode != 0;
   const bool aligned = ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(xt) | reinterpret_cast<uintptr_t>(coef_s) |
                          reinterpret_cast<uintptr_t>(coef_t) | reinterpret_cast<uintptr_t>(grad_xs) |
                          reinterpret_cast<uintptr_t>(grad_xt)) & 15) == 0;
-  if (wide_ok && aligned && n % 4 == 0 && m % 4 == 0 && n >= 4 && m >= 4) {
+  // ... and launches that fill the chip with 256-point workgroups (two per CU): a small grid -- the notebooks' one pair of
+  // 1200 points -- is latency, and the one-point-per-lane kernel has four times the workgroups (9.3 against 15.2 us there)
+  const long wide_groups = (long)((n + 255) / 256 + (m + 255) / 256) * pairs;
+  if (wide_ok && aligned && n % 4 == 0 && m % 4 == 0 && n >= 4 && m >= 4 && (wide_groups >= 512 || wide_mode == 2)) {
     const int c_s = (n + 255) / 256, c_t = (m + 255) / 256;
     for (int b0 = 0; b0 < pairs; b0 += 65535) {
       const int nb = pairs - b0 < 65535 ? pairs - b0 : 65535;
