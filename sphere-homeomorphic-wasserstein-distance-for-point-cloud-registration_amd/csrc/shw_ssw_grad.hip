@@ -163,7 +163,8 @@ __global__ __launch_bounds__(WAVES * 64, grad_waves_per_simd(EPT)) void ssw_forw
 // in wave order through LDS -- fixed order, no atomics, bitwise reproducible.  Directions are
 // wave-uniform scalar loads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* __restrict__ xs,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void ssw_backward_points_kernel(const float* __restrict__ xs,
                                                                   const float* __restrict__ xt,
                                                                   const float* __restrict__ dirs,
                                                                   const float* __restrict__ coef_s,
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
                                                                   const float* __restrict__ total_w,
                                                                   float* __restrict__ grad_xs,
                                                                   float* __restrict__ grad_xt, int chunks_s) {
-  __shared__ float part[3][4][64];
+  // NW waves split the slices NW ways: 4 for grids that fill the chip, 16 for small ones (the notebooks' one pair x 100
+  // slices: 6 slices per wave, one round of loads instead of four)
+  __shared__ float part[3][NW][64];
   const int b = blockIdx.y;
   const bool is_t = (int)blockIdx.x >= chunks_s;
   const int chunk = is_t ? blockIdx.x - chunks_s : blockIdx.x;
@@ -202,14 +205,22 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
     gz = fmaf(w, fmaf(a, U[5], -bb * U[4]), gz);
   };
   int l = wave;
-  for (; l + 28 < slices; l += 32) {                 // 8 slices of this wave per trip, loads first
+  for (; l + 7 * NW < slices; l += 8 * NW) {         // 8 slices of this wave per trip, loads first
     float c[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = C[(long)(l + 4 * j) * cnt + ic];
+    for (int j = 0; j < 8; ++j) c[j] = C[(long)(l + NW * j) * cnt + ic];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) add(c[j], Ub + (long)(l + 4 * j) * 6);
+    for (int j = 0; j < 8; ++j) add(c[j], Ub + (long)(l + NW * j) * 6);
   }
-  for (; l < slices; l += 4) add(C[(long)l * cnt + ic], Ub + (long)l * 6);
+  if (l < slices) {                                  // the last, partial trip: the same loads, clamped, then only the live ones
+    float c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = C[(long)min(l + NW * j, slices - 1) * cnt + ic];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (l + NW * j < slices) add(c[j], Ub + (long)(l + NW * j) * 6);   // (wave-uniform)
+    }
+  }
   part[0][wave][lane] = gx;
   part[1][wave][lane] = gy;
   part[2][wave][lane] = gz;
@@ -221,8 +232,12 @@ __global__ __launch_bounds__(256) void ssw_backward_points_kernel(const float* _
     if (total_w) up += total_w[0];
     const float sc = scale * up;
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-      G[3 * i + d] = (((part[d][0][lane] + part[d][1][lane]) + part[d][2][lane]) + part[d][3][lane]) * sc;
+    for (int d = 0; d < 3; ++d) {
+      float acc = part[d][0][lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) acc += part[d][w][lane];                // wave order: fixed
+      G[3 * i + d] = acc * sc;
+    }
   }
 }
 
@@ -411,10 +426,17 @@ int launch_backward_points(const float* xs, const float* xt, const float* dirs, 
   // pairs ride on gridDim.y (<= 65535): larger batches go out as several launches over pair blocks
   for (int b0 = 0; b0 < pairs; b0 += 65535) {
     const int nb = pairs - b0 < 65535 ? pairs - b0 : 65535;
-    hipLaunchKernelGGL(ssw_backward_points_kernel, dim3(chunks_s + chunks_t, nb), dim3(256), 0, stream,
-                       xs + (long)b0 * n * 3, xt + (long)b0 * m * 3, dirs + (long)b0 * u_pair_stride,
-                       coef_s + (long)b0 * slices * n, coef_t + (long)b0 * slices * m, n, m, slices, u_pair_stride,
-                       scale, pair_w ? pair_w + b0 : nullptr, total_w, grad_xs + (long)b0 * n * 3, grad_xt + (long)b0 * m * 3, chunks_s);
+    // fewer workgroups than CUs: sixteen waves per workgroup share the slices
+    if ((long)(chunks_s + chunks_t) * pairs < 256 && slices >= 32)
+      hipLaunchKernelGGL(ssw_backward_points_kernel<16>, dim3(chunks_s + chunks_t, nb), dim3(1024), 0, stream,
+                         xs + (long)b0 * n * 3, xt + (long)b0 * m * 3, dirs + (long)b0 * u_pair_stride,
+                         coef_s + (long)b0 * slices * n, coef_t + (long)b0 * slices * m, n, m, slices, u_pair_stride,
+                         scale, pair_w ? pair_w + b0 : nullptr, total_w, grad_xs + (long)b0 * n * 3, grad_xt + (long)b0 * m * 3, chunks_s);
+    else
+      hipLaunchKernelGGL(ssw_backward_points_kernel<4>, dim3(chunks_s + chunks_t, nb), dim3(256), 0, stream,
+                         xs + (long)b0 * n * 3, xt + (long)b0 * m * 3, dirs + (long)b0 * u_pair_stride,
+                         coef_s + (long)b0 * slices * n, coef_t + (long)b0 * slices * m, n, m, slices, u_pair_stride,
+                         scale, pair_w ? pair_w + b0 : nullptr, total_w, grad_xs + (long)b0 * n * 3, grad_xt + (long)b0 * m * 3, chunks_s);
   }
   return (int)hipGetLastError();
 }

@@ -495,7 +495,7 @@ import json, sys, hashlib, torch
 sys.path.insert(0, sys.argv[1])
 import shw_amd
 out = {}
-for (B, n, m, L, p) in ((3, 1200, 1200, 37, 2), (2, 2048, 1024, 16, 1), (1, 4, 8, 5, 2), (2, 3000, 3000, 9, 2), (2, 1200, 900, 8, 2)):
+for (B, n, m, L, p) in ((8, 1200, 1200, 37, 2), (2, 2048, 1024, 16, 1), (1, 4, 8, 5, 2), (2, 3000, 3000, 9, 2), (2, 1200, 900, 8, 2)):
     g = torch.Generator().manual_seed(100 * n + m)
     x = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=g), dim=-1).cuda().requires_grad_(True)
     y = torch.nn.functional.normalize(torch.randn(B, m, 3, generator=g), dim=-1).cuda().requires_grad_(True)
@@ -511,7 +511,9 @@ def test_wide_backward_points_kernel_is_bit_identical_to_the_one_point_per_lane_
     """Sizes that are multiples of 4 take `ssw_backward_points4_kernel` (a lane owns four consecutive points, 16-byte
     coefficient loads).  It adds the slices of a point in the same order as the one-point-per-lane kernel
     (`SHW_BWD_WIDE=0`): the gradients of both clouds must be the same BITS, for equal and unequal sizes, p = 1 and 2, sizes
-    above 2048 and the smallest size that qualifies."""
+    above 2048 and the smallest size that qualifies.  (Shapes chosen so that the one-point-per-lane kernel runs in its
+    four-wave form: with fewer than 256 workgroups and at least 32 slices it splits the slices over sixteen waves, another
+    order of the sixteen partial sums.)"""
     res = {}
     for wide in ("0", "2"):                         # never / whenever sizes and alignment allow (the default also asks
         env = dict(os.environ, SHW_BWD_WIDE=wide)   # for a grid that fills the chip)
