@@ -1,5 +1,5 @@
 """the distribution sort assumes ~2 keys per bin and sends a slice to the bitonic network when any bin holds
-more than 24 keys -- kernel time is data dependent.  This times the headline loss kernel (B=64, N=2048, L=512, p=2) on
+more than 24 (round 3: 40) keys -- kernel time is data dependent.  This times the headline loss kernel (B=64, N=2048, L=512, p=2) on
 cloud families that are NOT uniform in angle, and -- with a library built with -DSHW_DBG_RUNLEN (slice_shift then reports
 the longest equal-bin run of the slice's two sorts) -- the distribution of that run length and the share of slices that
 took the fallback.
@@ -62,6 +62,7 @@ def family(name):
 
 names = ["gaussian sphere (bench.py)", "cube surface (the notebooks)", "CAD-like: 6 planes + 2 cylinders, centred, unit scale",
          "16 tight clusters on the sphere (sigma 0.02)", "great circle band (|z| < 0.02)", "64 distinct points, each 32 times"]
+MAX_RUN = int(os.environ.get("SHW_BINSORT_MAX_RUN", "40"))      # csrc/bin_sort.hpp (a compile-time constant of the library)
 U = shw.draw_directions(L, dev, batch=B, d=3)
 print("library:", os.path.basename(os.environ.get("SHW_LIB_PATH", "default")))
 for name in names:
@@ -73,5 +74,6 @@ for name in names:
         run = aux.flatten().float()
         q = torch.quantile(run, torch.tensor([0.5, 0.9, 0.99], device=dev))
         line += (f" | longest run: median {q[0]:.0f}, p90 {q[1]:.0f}, p99 {q[2]:.0f}, max {run.max():.0f}; "
-                 f"fallback (run > 24) {100 * (run > 24).float().mean():.2f} % of slices")
+                 f"network fallback (run > {MAX_RUN}, SHW_BINSORT_MAX_RUN of this build) {100 * (run > MAX_RUN).float().mean():.2f} % of slices"
+                 f" (run > 24, round 2's threshold: {100 * (run > 24).float().mean():.2f} %)")
     print(line, flush=True)
