@@ -563,3 +563,57 @@ def test_keys_per_lane_classes_agree_with_the_power_of_two_classes(shw):
             assert np.all(np.abs(ca - cb) <= 3e-6 * np.abs(cb) + 1e-12), (key, f)
         for f in ("gx", "gy"):
             grad_close(np.array(a[f]), np.array(b[f]), strict=2e-5, loose=5e-2, frac=0.002)
+
+
+# ------------------------------------------------------------------------------- clouds that are not uniform in angle
+def _nonuniform_cloud(kind, gen, B, n):
+    """The families of tools/nonuniform_time.py (profiles/r03_nonuniform.txt): their circle coordinates crowd into few bins
+    of the distribution sort -- equal-bin runs of 20..40 keys are fixed up by odd-even phases, longer ones send the slice
+    to the bitonic network (csrc/bin_sort.hpp, SHW_BINSORT_MAX_RUN)."""
+    x = torch.randn(B, n, 3, generator=gen)
+    if kind == "cube_surface":                       # Flow_cube.ipynb:127-200: faces of [0, 1]^3, un-normalised, not centred
+        face = torch.randint(0, 3, (B, n), generator=gen)
+        pts = torch.rand(B, n, 3, generator=gen)
+        pts.scatter_(2, face.unsqueeze(-1), torch.randint(0, 2, (B, n, 1), generator=gen).float())
+        return pts
+    if kind == "tight_clusters":
+        centres = torch.nn.functional.normalize(torch.randn(B, 16, 3, generator=gen), dim=-1)
+        pick = torch.randint(0, 16, (B, n), generator=gen)
+        return torch.nn.functional.normalize(torch.gather(centres, 1, pick.unsqueeze(-1).expand(B, n, 3)) + 0.02 * x, dim=-1)
+    if kind == "great_circle_band":
+        x[..., 2] *= 0.02
+        return torch.nn.functional.normalize(x, dim=-1)
+    if kind == "duplicates_32_fold":
+        base = torch.nn.functional.normalize(torch.randn(B, n // 32, 3, generator=gen), dim=-1)
+        return base.repeat(1, 32, 1)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["cube_surface", "tight_clusters", "great_circle_band", "duplicates_32_fold"])
+@pytest.mark.parametrize("p", [2, 1])
+def test_headline_kernels_on_clouds_not_uniform_in_angle_against_cpu_oracle(shw, kind, p):
+    """ADVICE r2 (data-dependent sort path): the one-wave kernels of the headline shape (N = M = 2048, the full 32-keys-per-lane
+    class; 4 pairs x 300 slices, above the small-grid limit) on clouds whose slices take the long odd-even fix-up or the
+    network fallback, against the float64 oracle on a sample of slices (2e-5 per slice), and the loss-only kernel against
+    the training kernel on every slice (the two carry different sorts: keys only / keys with indices)."""
+    from oracle import exact_shift
+    gen = torch.Generator().manual_seed(4242 + len(kind) + int(p))
+    B, n, L = 4, 2048, 300
+    x, y, U = _nonuniform_cloud(kind, gen, B, n), _nonuniform_cloud(kind, gen, B, n), directions(gen, B, L)
+    with torch.no_grad():
+        _, cost_fwd, _ = shw.ssw_pair_losses(x.cuda(), y.cuda(), U.cuda(), p=p, return_slices=True)
+    xs, ys = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    pair, cost, _ = shw.ssw_pair_losses(xs, ys, U.cuda(), p=p, return_slices=True)
+    sample = [0, 1, 77, 150, 298, 299]
+    for b in (0, 3):
+        cu = exact_shift.circle_coords(x[b].numpy(), U[b, sample].numpy())
+        cv = exact_shift.circle_coords(y[b].numpy(), U[b, sample].numpy())
+        if p == 1:
+            ref64 = np.array([exact_shift.w1_level_median(cu[i], cv[i]) for i in range(len(sample))])
+        else:
+            ref64, _ = exact_shift.circular_ot_equal(cu, cv, p=p)
+        got = cost_fwd[b, sample].cpu().numpy()
+        assert np.allclose(got, ref64, rtol=2e-5, atol=1e-9), (kind, b, rel(got, ref64))
+    assert torch.allclose(cost_fwd, cost.detach(), rtol=3e-6 if p == 2 else 1e-4, atol=1e-10)
+    pair.sum().backward()
+    assert torch.isfinite(xs.grad).all() and torch.isfinite(ys.grad).all()
